@@ -220,13 +220,15 @@ def init_params(cfg, seed, *, noise_bias=True):
         elif i == 4 + 16 * cfg.num_layers:
             is_gamma = True
         if is_gamma:
-            v = 1.0 + (rng.standard_normal(n) * 0.05 if noise_bias else 0.0)
+            v = 1.0 + (rng.standard_normal(n) * 0.05 if noise_bias else np.zeros(n))
         elif s[0] == 1 and len(s) == 2:
             v = rng.standard_normal(n) * 0.02 if noise_bias else np.zeros(n)
         else:
             v = rng.standard_normal(n) * 0.02
         out.append(np.asarray(v, dtype=np.float32).reshape(-1))
-    return np.concatenate(out)
+    flat = np.concatenate(out)
+    assert len(flat) == sum(int(np.prod(s)) for s in shapes)
+    return flat
 
 
 def relerr(a, b):
@@ -241,3 +243,160 @@ def max_relerr(a, b, floor=None):
     b = np.asarray(b, dtype=np.float64)
     scale = float(np.max(np.abs(b))) if floor is None else max(float(np.max(np.abs(b))), floor)
     return float(np.max(np.abs(a - b)) / max(scale, 1e-30))
+
+
+# ----------------------------------------------------------------------------- golden helpers
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+TINY = dict(image_size=28, patch_size=14, in_channels=1, num_classes=10, embedding_dim=32, num_heads=4,
+            num_layers=2, mlp_hidden_dim=64)
+
+
+def tensor_digest(flat, shapes, nsamp=64):
+    """Per-tensor (float64 sum, L2 norm, nsamp strided samples) of a flat parameter-ordered vector."""
+    sums, norms, samples = [], [], []
+    off = 0
+    for shp in shapes:
+        k = int(np.prod(shp))
+        t = np.asarray(flat[off:off + k], dtype=np.float64)
+        idx = np.linspace(0, k - 1, min(k, nsamp)).astype(np.int64)
+        s = np.zeros(nsamp, dtype=np.float32)
+        s[:len(idx)] = flat[off:off + k][idx]
+        sums.append(t.sum()); norms.append(np.sqrt((t * t).sum())); samples.append(s)
+        off += k
+    return np.array(sums), np.array(norms), np.stack(samples)
+
+
+def check_digest(flat, shapes, sums, norms, samples, tol, what=""):
+    """Assert a flat vector matches a stored digest: samples and norm to `tol` relative to the
+    tensor's scale, sum to tol * sqrt(k) * scale (a sum of k rounding errors)."""
+    off = 0
+    for i, shp in enumerate(shapes):
+        k = int(np.prod(shp))
+        t = np.asarray(flat[off:off + k], dtype=np.float64)
+        idx = np.linspace(0, k - 1, min(k, samples.shape[1])).astype(np.int64)
+        scale = max(float(np.max(np.abs(t))), float(np.max(np.abs(samples[i]))), 1e-30)
+        got = t[idx]
+        err = float(np.max(np.abs(got - samples[i][:len(idx)]))) / scale
+        assert err <= tol, f"{what} tensor {i} {shp}: sample err {err:.3e} > {tol}"
+        nerr = abs(np.sqrt((t * t).sum()) - norms[i]) / max(norms[i], 1e-30)
+        assert nerr <= tol, f"{what} tensor {i} {shp}: norm err {nerr:.3e} > {tol}"
+        serr = abs(t.sum() - sums[i]) / (scale * np.sqrt(k))
+        assert serr <= tol, f"{what} tensor {i} {shp}: sum err {serr:.3e} > {tol}"
+        off += k
+
+
+def read_weights_file(path, shapes=None):
+    """Parse the reference's .weights format (ModelUtils.cpp:28-51 of the reference): per tensor
+    u64 rank, u64 dims[rank], f32 data[prod(dims)], native endian, no header."""
+    raw = open(path, "rb").read()
+    off, flat, got = 0, [], []
+    while off < len(raw):
+        rank = int(np.frombuffer(raw, np.uint64, 1, off)[0]); off += 8
+        dims = tuple(int(d) for d in np.frombuffer(raw, np.uint64, rank, off)); off += 8 * rank
+        n = int(np.prod(dims))
+        flat.append(np.frombuffer(raw, np.float32, n, off)); off += 4 * n
+        got.append(dims)
+    if shapes is not None:
+        assert [tuple(s) for s in shapes] == got, "checkpoint tensor shapes do not match the config"
+    return np.concatenate(flat).astype(np.float32), got
+
+
+def write_weights_file(path, flat, shapes):
+    with open(path, "wb") as f:
+        off = 0
+        for shp in shapes:
+            n = int(np.prod(shp))
+            f.write(np.uint64(len(shp)).tobytes())
+            f.write(np.asarray(shp, dtype=np.uint64).tobytes())
+            f.write(np.asarray(flat[off:off + n], dtype=np.float32).tobytes())
+            off += n
+
+
+# ------------------------------------------------------------------ shared golden-case inputs
+def op_case(name):
+    """Seeded inputs of the op-level golden cases (tests/golden/ops.npz holds the reference's outputs)."""
+    if name == "dense":
+        rows, i, o = 24, 49, 40
+        return dict(rows=rows, i=i, o=o, W=rng_normal(1, i, o, scale=0.05), b=rng_normal(2, 1, o, scale=0.05),
+                    x=rng_normal(3, rows, i), dy=rng_normal(4, rows, o))
+    if name == "ln":
+        rows, D = 50, 96
+        return dict(rows=rows, D=D, g=1 + rng_normal(5, 1, D, scale=0.1), b=rng_normal(6, 1, D, scale=0.1),
+                    x=rng_normal(7, rows, D) * 2 + 0.3, dy=rng_normal(8, rows, D))
+    if name == "gelu":
+        return dict(n=2048, x=rng_normal(9, 2048) * 3, dy=rng_normal(10, 2048))
+    if name == "softmax":
+        return dict(b=6, n=17, x=rng_normal(11, 6, 17, 17) * 3, g=rng_normal(12, 6, 17, 17))
+    if name in ("mha_a", "mha_b"):
+        D, h, B, N = {"mha_a": (96, 8, 3, 5), "mha_b": (64, 8, 2, 17)}[name]
+        n = 4 * (D * D + D)
+        return dict(D=D, h=h, B=B, N=N, n=n, prm=rng_normal(13, n, scale=0.2), x=rng_normal(14, B, N, D),
+                    dy=rng_normal(15, B, N, D))
+    if name in ("ffn", "block"):
+        D, H, h, B, N = 64, 160, 8, 3, 5
+        n = D * H + H + H * D + D
+        d = dict(D=D, H=H, h=h, B=B, N=N, x=rng_normal(17, B, N, D), dy=rng_normal(18, B, N, D))
+        if name == "ffn":
+            d.update(n=n, prm=rng_normal(16, n, scale=0.1))
+        else:
+            nb = 4 * D + 4 * (D * D + D) + n
+            prm = rng_normal(19, nb, scale=0.1)
+            prm[:D] += 1
+            prm[2 * D + 4 * (D * D + D):3 * D + 4 * (D * D + D)] += 1
+            d.update(n=nb, prm=prm)
+        return d
+    if name in ("emb_a", "emb_b", "emb_c"):
+        img, P, Cc, D, B = {"emb_a": (28, 14, 1, 96, 4), "emb_b": (28, 7, 3, 48, 3), "emb_c": (32, 16, 3, 40, 2)}[name]
+        N, pd = (img // P) ** 2 + 1, P * P * Cc
+        n = pd * D + D + D + N * D
+        return dict(img=img, P=P, C=Cc, D=D, B=B, N=N, pd=pd, n=n, prm=rng_normal(20, n, scale=0.05),
+                    x=rng_normal(21, B, Cc, img, img), dy=rng_normal(22, B, N, D))
+    if name == "ce":
+        B, K = 37, 10
+        w = np.abs(rng_normal(25, K)) + 0.1
+        w /= w.sum()
+        return dict(B=B, K=K, lg=rng_normal(23, B, K) * 2,
+                    y=onehot(np.random.default_rng(24).integers(0, K, B), K), w=w.astype(np.float32))
+    if name == "adam":
+        r, c, steps = 7, 9, 5
+        return dict(r=r, c=c, steps=steps, p=rng_normal(26, r, c), grads=rng_normal(27, steps, r, c),
+                    lrs=np.array([0.0, 1e-4, 3e-4, 3e-4, 2e-4], dtype=np.float32))
+    raise KeyError(name)
+
+
+def model_case_inputs(cfgd, B, seed, steps):
+    """Inputs of tests/golden/model_*.npz: params, first batch, per-step batches and learning rates."""
+    cfg = Cfg.make(**cfgd)
+    K = cfg.num_classes
+    shape = (B, cfg.in_channels, cfg.image_size, cfg.image_size)
+    d = dict(cfg=cfg, prm=init_params(cfg, seed), w=np.full(K, 1.0 / K, np.float32),
+             x=rng_normal(seed + 1, *shape), y=onehot(np.random.default_rng(seed + 2).integers(0, K, B), K))
+    d["xs"] = [rng_normal(seed + 10 + t, *shape) for t in range(steps)]
+    d["ys"] = [onehot(np.random.default_rng(seed + 50 + t).integers(0, K, B), K) for t in range(steps)]
+    return d
+
+
+MODEL_CASES = {  # name -> (config, B, seed, steps, full_grads)
+    "tiny_b4": (TINY, 4, 300, 3, True),
+    "c1_b8": (CONFIGS["C1"], 8, 400, 3, False),
+    "c2_b4": (CONFIGS["C2"], 4, 500, 2, False),
+    "ck_b4": (CONFIGS["CK"], 4, 600, 2, False),
+}
+
+
+def loss_curve_inputs():
+    """Inputs of tests/golden/loss_curve_c1_b32.npz (20 steps, C1, B=32, learnable template task)."""
+    cfg = Cfg.make(**CONFIGS["C1"])
+    B, steps, seed = 32, 20, 77
+    templ = rng_normal(seed + 1, 10, 1, 28, 28)
+    xs, ys = [], []
+    for t in range(steps):
+        lab = np.random.default_rng(seed + 100 + t).integers(0, 10, B)
+        xs.append((templ[lab] + 0.5 * rng_normal(seed + 200 + t, B, 1, 28, 28)).astype(np.float32))
+        ys.append(onehot(lab, 10))
+    return dict(cfg=cfg, B=B, steps=steps, prm=init_params(cfg, seed, noise_bias=False),
+                w=np.full(10, 0.1, np.float32), xs=xs, ys=ys)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
