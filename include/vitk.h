@@ -1,0 +1,202 @@
+/*
+ * vitk.h -- C-ABI of libvitk.so: the hand-written gfx950 (MI355X / CDNA4) kernels behind the ViT
+ * training step of PaulParizacaMozo/VisionTransformer.
+ *
+ * This is the accelerator boundary: plain device pointers, sizes and a HIP stream handle; no C++
+ * or torch types.  It plays the role the reference's own `*_cuda(const Tensor&)` op library plays
+ * in its CUDA tree (cuda_Vit/include/utils/CudaUtils.cuh:15-53), except that tensors stay
+ * device-resident, nothing here allocates or frees memory, and nothing synchronises the stream.
+ * Each entry point cites the reference CPU function (file:line in the reference tree) whose
+ * arithmetic it reproduces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; vitk_last_error() gives the
+ *     message of the calling thread's last failure (the C++ host layer turns it into
+ *     std::runtime_error, the reference's error convention, app/main.cpp:76-79);
+ *   - all tensors are float32, row-major, in device memory (hipMalloc or equivalent);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - workspaces are caller-provided; the *_workspace_bytes() helpers give their sizes.
+ */
+#ifndef VITK_H
+#define VITK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *vitk_stream_t;
+
+/* ---- library -------------------------------------------------------------------------------- */
+int vitk_version(void);
+const char *vitk_last_error(void);
+/* Select `device` for the calling thread and verify that it is a gfx950 part. */
+int vitk_init(int device);
+
+/* ---- dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) --------------------
+ * C[b] = epilogue(alpha * op(A[b]) * op(B[b])) for b in [0, batch).
+ * Replaces matrixMultiply (src/core/Tensor.cpp:472-504) and batchMatrixMultiply (:510-544) and,
+ * through the epilogue, the addBroadcast bias add (:435-445, Dense.cpp:43,53), GELU forward and
+ * backward (src/activations/GELU.cpp:13-42, 44-81) and the residual adds of
+ * TransformerEncoderBlock (src/model/TransformerEncoderBlock.cpp:28,34).  Transposed operands
+ * are addressed in place -- the reference's transpose()+contiguous() copies never materialise.
+ *
+ *   trans_a = 0: A is [M][K] (lda >= K)     trans_a = 1: A is [K][M] (lda >= M)
+ *   trans_b = 0: B is [K][N] (ldb >= N)     trans_b = 1: B is [N][K] (ldb >= K)
+ *   batch index b = bo * batch_inner + bi; operand X of batch b starts at
+ *   X + bo * stride_x_outer + bi * stride_x_inner (elements).  batch = batch_outer*batch_inner.
+ *
+ * Epilogue, in this order, per element (m, n):
+ *   v = alpha * acc
+ *   act == VITK_ACT_GELU_BWD:  v = v * gelu'(aux[m][n])               (aux is an input)
+ *   bias != NULL:              v += bias[n]
+ *   act == VITK_ACT_GELU_FWD:  if (aux) aux[m][n] = v;  v = gelu(v)   (aux is an output)
+ *   residual != NULL:          v += residual[m][n]
+ *   C[m][n] = v
+ * split_k > 1 (or 0 = let the library choose) splits the contraction over several workgroups;
+ * partial tiles go to `workspace` and are summed in a fixed order by a second kernel, so results
+ * do not depend on scheduling.  Split-K requires alpha == 1 and no bias/act/residual.
+ */
+enum { VITK_ACT_NONE = 0, VITK_ACT_GELU_FWD = 1, VITK_ACT_GELU_BWD = 2 };
+
+typedef struct vitk_gemm_args {
+  int32_t trans_a, trans_b;
+  int32_t M, N, K;
+  const float *A;
+  int64_t lda;
+  const float *B;
+  int64_t ldb;
+  float *C;
+  int64_t ldc;
+  float alpha;
+  int32_t act;
+  const float *bias;
+  const float *residual;
+  int64_t ldr;
+  float *aux;
+  int64_t ldaux;
+  int32_t batch_outer, batch_inner; /* 0 is treated as 1 */
+  int64_t stride_a_outer, stride_a_inner;
+  int64_t stride_b_outer, stride_b_inner;
+  int64_t stride_c_outer, stride_c_inner;
+  int32_t split_k; /* 1 = none, 0 = auto */
+  int32_t reserved;
+  float *workspace;
+  size_t workspace_bytes;
+} vitk_gemm_args;
+
+int vitk_gemm_f32(const vitk_gemm_args *args, vitk_stream_t stream);
+/* Bytes of workspace vitk_gemm_f32 needs for these arguments (0 when it will not split K). */
+size_t vitk_gemm_workspace_bytes(const vitk_gemm_args *args);
+
+/* ---- column sum: out[j] = sum_i x[i][j]  (Tensor::sum(0), src/core/Tensor.cpp:385-430; the
+ * bias gradient of Dense::backward, src/layers/Dense.cpp:95, and dpos/dcls of
+ * Embeddings::backward, src/layers/Embeddings.cpp:43,50).  Two-stage, fixed order.
+ * workspace: vitk_colsum_workspace_bytes(rows, cols). */
+size_t vitk_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int vitk_colsum_f32(const float *x, int64_t rows, int64_t cols, int64_t ldx, float *out, float *workspace,
+                    size_t workspace_bytes, vitk_stream_t stream);
+
+/* ---- LayerNorm (src/layers/LayerNorm.cpp:24-89 forward, :91-163 backward) ---------------------
+ * forward: two-pass mean / biased variance per row, inv_std = 1/sqrt(var+eps),
+ * y = gamma * (x-mean)*inv_std + beta.  mean / inv_std ([rows], may be NULL for inference) are
+ * what backward needs; x-hat is recomputed there instead of being stored.
+ * backward: dx = (1/D)*inv_std*(D*dxhat - sum(dxhat) - xhat*sum(dxhat*xhat)), dxhat = dy*gamma;
+ * if `residual` is non-NULL it is added to dx (the skip branch of the block's backward,
+ * src/model/TransformerEncoderBlock.cpp:52,63).  dgamma/dbeta are reduced over rows in two
+ * fixed-order stages.  Rows are `row_stride` elements apart (row_stride >= D). */
+size_t vitk_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D);
+int vitk_layernorm_fwd(const float *x, int64_t rows, int64_t D, int64_t row_stride, const float *gamma,
+                       const float *beta, float eps, float *y, float *mean, float *inv_std, vitk_stream_t stream);
+int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *inv_std, const float *gamma,
+                       int64_t rows, int64_t D, int64_t row_stride, const float *residual, float *dx, float *dgamma,
+                       float *dbeta, float *workspace, size_t workspace_bytes, vitk_stream_t stream);
+
+/* ---- GELU, tanh approximation (src/activations/GELU.cpp:9,13-42,44-81) ------------------------ */
+int vitk_gelu_fwd(const float *x, int64_t n, float *y, vitk_stream_t stream);
+int vitk_gelu_bwd(const float *x, const float *dy, int64_t n, float *dx, vitk_stream_t stream);
+
+/* ---- inverted dropout (src/layers/Dropout.cpp:21-59 forward, :61-87 backward) -----------------
+ * mask[i] = 0 with probability `rate`, else 1/(1-rate); y = x*mask.  The reference draws from a
+ * random_device-seeded mt19937, so only the distribution can be matched: the device stream is
+ * Philox4x32-10 keyed by (seed, offset + element index / 4). */
+int vitk_dropout_fwd(const float *x, int64_t n, float rate, uint64_t seed, uint64_t offset, float *y, float *mask,
+                     vitk_stream_t stream);
+int vitk_dropout_bwd(const float *dy, const float *mask, int64_t n, float *dx, vitk_stream_t stream);
+
+/* ---- element-wise helpers (Tensor::operator+, src/core/Tensor.cpp:316-351; fill :128-137) ----- */
+int vitk_add_f32(const float *a, const float *b, int64_t n, float *out, vitk_stream_t stream);
+int vitk_add3_f32(const float *a, const float *b, const float *c, int64_t n, float *out, vitk_stream_t stream);
+int vitk_scale_f32(const float *x, float s, int64_t n, float *out, vitk_stream_t stream);
+int vitk_fill_f32(float *x, float value, int64_t n, vitk_stream_t stream);
+/* strided 2-D copy: dst[r][c] = src[r][c], r < rows, c < cols (contiguous()/slice copies,
+ * src/core/Tensor.cpp:227-254). */
+int vitk_copy2d_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                    vitk_stream_t stream);
+
+/* ---- row softmax over the last axis and its backward (src/layers/MultiHeadAttention.cpp:123-156
+ * and :279-308).  Rows are ld elements apart; columns [n, ld) of the output are written as 0.
+ * backward: dx = scale * p * (g - sum_k g_k p_k). */
+int vitk_softmax_rows(const float *x, int64_t rows, int64_t n, int64_t ld, float *p, vitk_stream_t stream);
+int vitk_softmax_rows_bwd(const float *g, const float *p, int64_t rows, int64_t n, int64_t ld, float scale, float *dx,
+                          vitk_stream_t stream);
+
+/* ---- attention key-gradient layout of the reference --------------------------------------------
+ * MultiHeadAttention::backward computes Q^T dS as a [dh][N] buffer per (batch, head) and then
+ * re-reads that buffer as if it were [N][dh] (src/layers/MultiHeadAttention.cpp:207-222), so the
+ * key gradient the reference trains with is a permutation of the true dK = dS^T Q.
+ * VITK_DK_REFERENCE reproduces it; VITK_DK_EXACT is the mathematically correct gradient. */
+enum { VITK_DK_REFERENCE = 0, VITK_DK_EXACT = 1 };
+/* The re-read itself: t is [B*heads][dh][N] (= Q^T dS per head); writes
+ * dk[(b*N + n')*ld_dk + head*dh + d'] = t[bh][n'*dh + d' (flat index into the [dh][N] buffer)]. */
+int vitk_dk_reference_scatter(const float *t, int32_t B, int32_t heads, int32_t N, int32_t dh, float *dk,
+                              int64_t ld_dk, vitk_stream_t stream);
+
+/* ---- patch extraction (src/layers/PatchEmbedding.cpp:31-52) -----------------------------------
+ * img is [B][C][HW][HW]; patches is [B*Np][P*P*C], Np = (HW/P)^2.
+ * VITK_PATCH_REFERENCE: what the reference CPU path does -- patch (ph,pw) is the P*P*C CONTIGUOUS
+ * floats starting at flat offset ph*P*HW + pw*P of the image (not an im2col; for C > 1 only
+ * channel 0 is ever read).  VITK_PATCH_IM2COL: true ViT patches, element order (c, i, j), the
+ * layout the reference's CUDA tree uses (cuda_Vit/src/layers/Conv2d.cu:49-57). */
+enum { VITK_PATCH_REFERENCE = 0, VITK_PATCH_IM2COL = 1 };
+int vitk_patch_gather(const float *img, int32_t B, int32_t C, int32_t HW, int32_t P, int32_t mode, float *patches,
+                      vitk_stream_t stream);
+
+/* ---- embeddings (src/layers/Embeddings.cpp:24-40 forward, :42-74 backward) --------------------
+ * assemble: out[b][0][:] = cls + pos[0]; out[b][1+p][:] = proj[b*Np+p][:] + pos[1+p].
+ * split (backward): dproj[b*Np+p][:] = dy[b][1+p][:]   (dpos/dcls come from vitk_colsum_f32 over
+ * dy viewed as [B][N*D]). */
+int vitk_embed_assemble(const float *proj, const float *cls, const float *pos, int32_t B, int32_t Np, int32_t D,
+                        float *out, vitk_stream_t stream);
+int vitk_embed_split_bwd(const float *dy, int32_t B, int32_t Np, int32_t D, float *dproj, vitk_stream_t stream);
+
+/* ---- CLS token slice and its backward (src/model/VisionTransformer.cpp:35, :49-56) ------------
+ * gather: cls_rows[b][:] = x[b][0][:];  scatter: dx = 0 except dx[b][0][:] = dcls[b][:]. */
+int vitk_cls_gather(const float *x, int32_t B, int32_t N, int32_t D, float *cls_rows, vitk_stream_t stream);
+int vitk_cls_scatter(const float *dcls, int32_t B, int32_t N, int32_t D, float *dx, vitk_stream_t stream);
+
+/* ---- softmax cross-entropy, forward + backward fused (src/losses/CrossEntropy.cpp:20-111) -----
+ * probs = softmax(logits); loss = (1/B) sum_i -w[c_i] * log(probs[i][c_i] + 1e-12) over the
+ * entries where y == 1 (class weights scale the LOSS only); dlogits = (probs - y) / grad_batch
+ * (grad_batch = B on one device; the global batch under data parallelism).  Also counts rows
+ * whose first-maximum logit is a labelled class (Trainer.cpp:23-50).
+ * out2[0] = loss, out2[1] = number of correct rows (as float).  workspace: 2*B floats. */
+int vitk_softmax_ce(const float *logits, const float *y_onehot, int32_t B, int32_t K, const float *class_w,
+                    float grad_batch, float *dlogits, float *probs, float *out2, float *workspace,
+                    size_t workspace_bytes, vitk_stream_t stream);
+/* first index of the row maximum (app/test.cpp:103-112) */
+int vitk_argmax_rows(const float *x, int32_t B, int32_t K, int32_t *out, vitk_stream_t stream);
+
+/* ---- Adam with coupled L2 over a flat arena (src/optimizers/Adam.cpp:29-60) -------------------
+ * g' = g + wd*p (if wd > 0); m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2;
+ * p -= lr * (m/(1-beta1_t)) / (sqrt(v/(1-beta2_t)) + eps).  beta?_t = float(pow(beta, t)) is
+ * computed by the caller, as the reference does (:32-33).  grad_scale multiplies g first
+ * (1 normally; 1/world when averaging all-reduced gradients). */
+int vitk_adam_l2(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                 float beta1_t, float beta2_t, float eps, float wd, float grad_scale, vitk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H */

@@ -1,0 +1,525 @@
+"""GPU parity tests of every libvitk kernel, called through the C-ABI (ctypes) and checked against
+the CPU oracle (oracle/libvit_oracle.so), the committed golden vectors (tests/golden/ops.npz, made by
+the compiled reference) and float64 numpy.
+
+Tolerances (fp32 everywhere; stated relative to each tensor's max magnitude):
+  * element-wise / normalisation / optimiser kernels: 2e-6 (same formulas, correctly rounded
+    sqrt/div; only libm ulp differences and reduction order remain);
+  * matrix-core contractions: 1e-5 (k-ordered fp32 FMA chain vs the oracle's mul+add chain);
+  * composed layers (attention block): 2e-5.  The bar named by the task is 1e-4.
+"""
+import numpy as np
+import pytest
+
+import vitlibs as V
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def K():
+    from visiontransformer_amd import vitk
+    vitk.init(0)
+    return vitk
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def empty(*shape):
+    return torch.empty(shape, dtype=torch.float32, device="cuda")
+
+
+def close(got, want, tol):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.isfinite(got).all()
+    e = V.max_relerr(got, want)
+    assert e <= tol, f"max rel err {e:.3e} > {tol:.1e}"
+
+
+# ----------------------------------------------------------------------------------- GEMM
+def ref_gemm(a, b, ta, tb):
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    return (a64.T if ta else a64) @ (b64.T if tb else b64)
+
+
+def test_gemm_layout_identity_with_asymmetric_b(K):
+    # A = I, B asymmetric: catches a transposed accumulator map or swapped operands exactly
+    n = 96
+    a = np.eye(n, dtype=np.float32)
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251) - 17 * (np.arange(n)[:, None] % 3)
+    c = empty(n, n)
+    K.gemm(dev(a), dev(b), c, n, n, n)
+    np.testing.assert_array_equal(host(c), b)
+    K.gemm(dev(a), dev(b), c, n, n, n, trans_b=True)
+    np.testing.assert_array_equal(host(c), b.T)
+    K.gemm(dev(b), dev(a), c, n, n, n, trans_a=True)
+    np.testing.assert_array_equal(host(c), b.T)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,Kd", [(640, 96, 96), (257, 130, 75), (128, 128, 16), (33, 10, 147), (512, 384, 200),
+                                    (1000, 768, 49), (5, 5, 12), (197, 197, 64)])
+def test_gemm_shapes(K, ta, tb, M, N, Kd):
+    a = V.rng_normal(1, *((Kd, M) if ta else (M, Kd)))
+    b = V.rng_normal(2, *((N, Kd) if tb else (Kd, N)))
+    c = empty(M, N)
+    K.gemm(dev(a), dev(b), c, M, N, Kd, trans_a=bool(ta), trans_b=bool(tb))
+    close(host(c), ref_gemm(a, b, ta, tb), 1e-5)
+
+
+def test_gemm_matches_oracle_matmul(K):
+    O = V.oracle()
+    a, b = V.rng_normal(3, 300, 192), V.rng_normal(4, 192, 768) * 0.02
+    want = V.f32(300, 768)
+    O.vo_matmul(a, b, 300, 192, 768, want)
+    c = empty(300, 768)
+    K.gemm(dev(a), dev(b), c, 300, 768, 192)
+    close(host(c), want, 1e-5)
+
+
+def test_gemm_epilogues(K):
+    O = V.oracle()
+    M, N, Kd = 200, 160, 64
+    a, b = V.rng_normal(5, M, Kd), V.rng_normal(6, Kd, N) * 0.2
+    bias, res = V.rng_normal(7, N), V.rng_normal(8, M, N)
+    acc = ref_gemm(a, b, 0, 0)
+    c = empty(M, N)
+    K.gemm(dev(a), dev(b), c, M, N, Kd, bias=dev(bias), residual=dev(res), alpha=0.5)
+    close(host(c), 0.5 * acc + bias + res, 1e-5)
+    # GELU forward: aux receives the pre-activation, C its GELU
+    pre, act = empty(M, N), empty(M, N)
+    K.gemm(dev(a), dev(b), act, M, N, Kd, bias=dev(bias), act=K.ACT_GELU_FWD, aux=pre)
+    want_pre = (acc + bias).astype(np.float32)
+    close(host(pre), want_pre, 1e-5)
+    g = V.f32(M, N)
+    O.vo_gelu_forward(host(pre), M * N, g)
+    close(host(act), g, 2e-6)
+    # GELU backward: C = acc * gelu'(aux)
+    dx = empty(M, N)
+    K.gemm(dev(a), dev(b), dx, M, N, Kd, act=K.ACT_GELU_BWD, aux=pre)
+    gd = V.f32(M, N)
+    O.vo_gelu_backward(host(pre), acc.astype(np.float32), M * N, gd)
+    close(host(dx), gd, 1e-5)
+    # pitched operands and output (sub-matrices of larger buffers)
+    big_a, big_b, big_c = V.rng_normal(9, M, Kd + 12), V.rng_normal(10, Kd, N + 8), np.zeros((M, N + 4), np.float32)
+    dc = dev(big_c)
+    K.gemm(dev(big_a), dev(big_b), dc, M, N, Kd, lda=Kd + 12, ldb=N + 8, ldc=N + 4)
+    out = host(dc)
+    close(out[:, :N], ref_gemm(big_a[:, :Kd], big_b[:, :N], 0, 0), 1e-5)
+    assert (out[:, N:] == 0).all()
+
+
+@pytest.mark.parametrize("split", [0, 2, 7])
+def test_gemm_split_k_weight_gradient_shape(K, split):
+    # dW = X^T dY with a long contraction (rows) and a small output
+    rows, i, o = 5000, 96, 200
+    x, dy = V.rng_normal(11, rows, i), V.rng_normal(12, rows, o)
+    c = empty(i, o)
+    K.gemm(dev(x), dev(dy), c, i, o, rows, trans_a=True, split_k=split)
+    close(host(c), ref_gemm(x, dy, 1, 0), 1e-5)
+    c2 = empty(i, o)
+    K.gemm(dev(x), dev(dy), c2, i, o, rows, trans_a=True, split_k=split)
+    np.testing.assert_array_equal(host(c), host(c2))  # fixed reduction order: bitwise reproducible
+
+
+def test_gemm_batched_strided_heads(K):
+    # scores[b,h] = q[b,:,h,:] k[b,:,h,:]^T read straight out of a packed [B*N][3D] buffer
+    B, h, N, dh = 3, 4, 17, 8
+    D = h * dh
+    qkv = V.rng_normal(13, B * N, 3 * D)
+    dq = dev(qkv)
+    ld = 20
+    s = torch.zeros(B * h, N, ld, device="cuda")
+    K.gemm(dq, dq[:, D:], s, N, N, dh, trans_b=True, lda=3 * D, ldb=3 * D, ldc=ld, alpha=0.25, batch_outer=B,
+           batch_inner=h, stride_a=(N * 3 * D, dh), stride_b=(N * 3 * D, dh), stride_c=(h * N * ld, N * ld))
+    q = qkv[:, :D].reshape(B, N, h, dh).transpose(0, 2, 1, 3).astype(np.float64)
+    k = qkv[:, D:2 * D].reshape(B, N, h, dh).transpose(0, 2, 1, 3).astype(np.float64)
+    want = 0.25 * np.einsum("bhnd,bhmd->bhnm", q, k).reshape(B * h, N, N)
+    out = host(s)
+    close(out[:, :, :N], want, 1e-5)
+    assert (out[:, :, N:] == 0).all()
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,D", [(50, 96), (640, 64), (333, 768), (77, 192), (19, 1000), (9, 100), (6, 1030)])
+def test_layernorm_fwd_bwd_vs_oracle(K, rows, D):
+    O = V.oracle()
+    g, b = 1 + V.rng_normal(1, D) * 0.1, V.rng_normal(2, D) * 0.1
+    x, dy, res = V.rng_normal(3, rows, D) * 2 + 0.3, V.rng_normal(4, rows, D), V.rng_normal(5, rows, D)
+    y, xh, inv = V.f32(rows, D), V.f32(rows, D), V.f32(rows)
+    dg, db, dx = V.f32(D), V.f32(D), V.f32(rows, D)
+    O.vo_layernorm_forward(x, rows, D, g, b, 1e-5, y, xh, inv)
+    O.vo_layernorm_backward(dy, xh, inv, g, rows, D, dg, db, dx)
+    dX, dG, dB = dev(x), dev(g), dev(b)
+    Y, MU, INV = empty(rows, D), empty(rows), empty(rows)
+    K.call("vitk_layernorm_fwd", dX, rows, D, D, dG, dB, 1e-5, Y, MU, INV, K.stream())
+    close(host(Y), y, 2e-6)
+    close(host(INV), inv, 2e-6)
+    ws_bytes = K.dll().vitk_layernorm_bwd_workspace_bytes(rows, D)
+    ws = empty(ws_bytes // 4)
+    DX, DG, DB = empty(rows, D), empty(D), empty(D)
+    K.call("vitk_layernorm_bwd", dev(dy), dX, MU, INV, dG, rows, D, D, None, DX, DG, DB, ws, ws_bytes, K.stream())
+    close(host(DX), dx, 5e-6)
+    close(host(DG), dg, 5e-6)
+    close(host(DB), db, 5e-6)
+    K.call("vitk_layernorm_bwd", dev(dy), dX, MU, INV, dG, rows, D, D, dev(res), DX, DG, DB, ws, ws_bytes, K.stream())
+    close(host(DX), dx + res, 5e-6)
+
+
+def test_layernorm_golden_and_strided_rows(K):
+    g = V.golden("ops.npz")
+    c = V.op_case("ln")
+    rows, D = c["rows"], c["D"]
+    Y, MU, INV = empty(rows, D), empty(rows), empty(rows)
+    K.call("vitk_layernorm_fwd", dev(c["x"]), rows, D, D, dev(c["g"]), dev(c["b"]), 1e-5, Y, MU, INV, K.stream())
+    close(host(Y), g["ln_y"], 2e-6)
+    ws_bytes = K.dll().vitk_layernorm_bwd_workspace_bytes(rows, D)
+    ws, DX, DG, DB = empty(ws_bytes // 4), empty(rows, D), empty(1, D), empty(1, D)
+    K.call("vitk_layernorm_bwd", dev(c["dy"]), dev(c["x"]), MU, INV, dev(c["g"]), rows, D, D, None, DX, DG, DB, ws,
+           ws_bytes, K.stream())
+    close(host(DX), g["ln_dx"], 5e-6); close(host(DG), g["ln_dgamma"], 5e-6); close(host(DB), g["ln_dbeta"], 5e-6)
+    # rows 3*D apart (token 0 of each image in a [B][3][D] stream)
+    x3 = V.rng_normal(9, rows, 3, D)
+    y3 = torch.zeros(rows, 3, D, device="cuda")
+    K.call("vitk_layernorm_fwd", dev(x3), rows, D, 3 * D, dev(c["g"]), dev(c["b"]), 1e-5, y3, None, None, K.stream())
+    O = V.oracle()
+    want = V.f32(rows, D)
+    O.vo_layernorm_forward(np.ascontiguousarray(x3[:, 0]), rows, D, c["g"], c["b"], 1e-5, want, None, None)
+    out = host(y3)
+    close(out[:, 0], want, 2e-6)
+    assert (out[:, 1:] == 0).all()
+
+
+# ------------------------------------------------------------------ element-wise kernels
+@pytest.mark.parametrize("n", [1, 7, 2048, 100003])
+def test_gelu_vs_oracle(K, n):
+    O = V.oracle()
+    x, dy = V.rng_normal(1, n) * 3, V.rng_normal(2, n)
+    y, dx = V.f32(n), V.f32(n)
+    O.vo_gelu_forward(x, n, y)
+    O.vo_gelu_backward(x, dy, n, dx)
+    Y, DX = empty(n), empty(n)
+    K.call("vitk_gelu_fwd", dev(x), n, Y, K.stream())
+    K.call("vitk_gelu_bwd", dev(x), dev(dy), n, DX, K.stream())
+    close(host(Y), y, 2e-6)
+    close(host(DX), dx, 2e-6)
+    if n == 2048:
+        g = V.golden("ops.npz")
+        c = V.op_case("gelu")
+        K.call("vitk_gelu_fwd", dev(c["x"]), n, Y, K.stream())
+        K.call("vitk_gelu_bwd", dev(c["x"]), dev(c["dy"]), n, DX, K.stream())
+        close(host(Y), g["gelu_y"], 2e-6); close(host(DX), g["gelu_dx"], 2e-6)
+
+
+def test_dropout(K):
+    n, rate = 1_000_003, 0.2
+    x = V.rng_normal(1, n)
+    Y, Mk = empty(n), empty(n)
+    K.call("vitk_dropout_fwd", dev(x), n, rate, 1234, 0, Y, Mk, K.stream())
+    m, y = host(Mk), host(Y)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    assert set(np.unique(m)) == {np.float32(0), scale}
+    assert abs((m == 0).mean() - rate) < 4 * np.sqrt(rate * (1 - rate) / n)
+    np.testing.assert_array_equal(y, x * m)
+    Y2, M2 = empty(n), empty(n)
+    K.call("vitk_dropout_fwd", dev(x), n, rate, 1234, 0, Y2, M2, K.stream())
+    np.testing.assert_array_equal(host(M2), m)  # same (seed, offset) => same mask
+    K.call("vitk_dropout_fwd", dev(x), n, rate, 1234, n, Y2, M2, K.stream())
+    assert (host(M2) != m).mean() > 0.2  # different offset => different stream
+    dy = V.rng_normal(2, n)
+    DX = empty(n)
+    K.call("vitk_dropout_bwd", dev(dy), Mk, n, DX, K.stream())
+    np.testing.assert_array_equal(host(DX), dy * m)
+    # misaligned, odd-length view takes the scalar path and gives the same mask prefix
+    Y3, M3 = empty(1001), empty(1001)
+    K.call("vitk_dropout_fwd", dev(x)[1:], 1001, rate, 1234, 0, Y3, M3, K.stream())
+    np.testing.assert_array_equal(host(M3), m[:1001])
+
+
+def test_add_scale_fill_copy(K):
+    n = 70001
+    a, b, c = V.rng_normal(1, n), V.rng_normal(2, n), V.rng_normal(3, n)
+    out = empty(n)
+    K.call("vitk_add_f32", dev(a), dev(b), n, out, K.stream())
+    np.testing.assert_array_equal(host(out), a + b)
+    K.call("vitk_add3_f32", dev(a), dev(b), dev(c), n, out, K.stream())
+    np.testing.assert_array_equal(host(out), (a + b) + c)
+    K.call("vitk_scale_f32", dev(a), 0.125, n, out, K.stream())
+    np.testing.assert_array_equal(host(out), a * np.float32(0.125))
+    K.call("vitk_fill_f32", out, 3.5, n, K.stream())
+    assert (host(out) == 3.5).all()
+    src = V.rng_normal(4, 37, 52)
+    dst = torch.zeros(37, 44, device="cuda")
+    K.call("vitk_copy2d_f32", dev(src), 52, dst, 44, 37, 40, K.stream())
+    o = host(dst)
+    np.testing.assert_array_equal(o[:, :40], src[:, :40])
+    assert (o[:, 40:] == 0).all()
+    K.call("vitk_add_f32", dev(a), dev(b), 0, out, K.stream())  # empty input is a no-op
+
+
+@pytest.mark.parametrize("rows,cols", [(5000, 768), (256, 3840), (1, 10), (37, 1000), (50432, 96)])
+def test_colsum(K, rows, cols):
+    x = V.rng_normal(1, rows, cols)
+    nb = K.dll().vitk_colsum_workspace_bytes(rows, cols)
+    ws, out = empty(max(nb // 4, 1)), empty(cols)
+    K.call("vitk_colsum_f32", dev(x), rows, cols, cols, out, ws, nb, K.stream())
+    want = x.astype(np.float64).sum(0)
+    assert np.max(np.abs(host(out) - want)) <= 2e-6 * np.abs(x).astype(np.float64).sum(0).max()
+
+
+# -------------------------------------------------------------------------------- softmax
+@pytest.mark.parametrize("rows,n,ld", [(6 * 17, 17, 17), (40, 197, 200), (13, 5, 8), (3, 1000, 1000)])
+def test_softmax_rows(K, rows, n, ld):
+    O = V.oracle()
+    x, g = V.rng_normal(1, rows, n) * 3, V.rng_normal(2, rows, n)
+    p, d = V.f32(rows, n), V.f32(rows, n)
+    O.vo_softmax_rows(x, rows, n, p)
+    O.vo_softmax_rows_backward(g, p, rows, n, d)
+    xp, gp = np.full((rows, ld), 9.0, np.float32), np.full((rows, ld), 9.0, np.float32)
+    xp[:, :n], gp[:, :n] = x, g
+    P, D = empty(rows, ld), empty(rows, ld)
+    K.call("vitk_softmax_rows", dev(xp), rows, n, ld, P, K.stream())
+    out = host(P)
+    close(out[:, :n], p, 2e-6)
+    assert (out[:, n:] == 0).all()
+    K.call("vitk_softmax_rows_bwd", dev(gp), P, rows, n, ld, 0.125, D, K.stream())
+    close(host(D)[:, :n], d * np.float32(0.125), 5e-6)
+    if (rows, n) == (102, 17):
+        gd = V.golden("ops.npz")
+        c = V.op_case("softmax")
+        K.call("vitk_softmax_rows", dev(c["x"]), rows, n, n, P, K.stream())
+        close(host(P), gd["softmax_p"].reshape(rows, n), 2e-6)
+        K.call("vitk_softmax_rows_bwd", dev(c["g"]), P, rows, n, n, 1.0, D, K.stream())
+        close(host(D), gd["softmax_dx"].reshape(rows, n), 5e-6)
+
+
+@pytest.mark.parametrize("B,Kc", [(37, 10), (256, 1000), (1, 8)])
+def test_softmax_ce_vs_oracle(K, B, Kc):
+    O = V.oracle()
+    lg = V.rng_normal(1, B, Kc) * 2
+    lab = np.random.default_rng(2).integers(0, Kc, B)
+    y = V.onehot(lab, Kc)
+    w = np.abs(V.rng_normal(3, Kc)) + 0.1
+    w = (w / w.sum()).astype(np.float32)
+    ws = empty(2 * B)
+    for ww in (w, None):
+        grad = V.f32(B, Kc)
+        loss = O.vo_cross_entropy(lg, y, B, Kc, ww, Kc if ww is not None else 0, grad)
+        DL, PR, out2 = empty(B, Kc), empty(B, Kc), empty(2)
+        K.call("vitk_softmax_ce", dev(lg), dev(y), B, Kc, None if ww is None else dev(ww), float(B), DL, PR, out2, ws,
+               2 * B * 4, K.stream())
+        o2 = host(out2)
+        assert abs(o2[0] - loss) <= 5e-6 * abs(loss)
+        close(host(DL), grad, 2e-6)
+        assert o2[1] == (lg.argmax(1) == lab).sum()
+        # a different gradient batch (data parallel: global batch) only rescales the gradient
+        K.call("vitk_softmax_ce", dev(lg), dev(y), B, Kc, None, float(4 * B), DL, None, out2, ws, 2 * B * 4, K.stream())
+        close(host(DL) * 4, grad, 2e-6)
+    if (B, Kc) == (37, 10):
+        g = V.golden("ops.npz")
+        c = V.op_case("ce")
+        DL, out2 = empty(B, Kc), empty(2)
+        K.call("vitk_softmax_ce", dev(c["lg"]), dev(c["y"]), B, Kc, dev(c["w"]), float(B), DL, None, out2, ws, 2 * B * 4,
+               K.stream())
+        assert abs(host(out2)[0] - g["ce_loss_w"]) <= 5e-6 * abs(g["ce_loss_w"])
+        close(host(DL), g["ce_grad"], 2e-6)
+
+
+def test_argmax_first_maximum(K):
+    B, Kc = 300, 1000
+    x = V.rng_normal(1, B, Kc)
+    x[3, 700] = x[3, 20] = 50.0  # tie: lowest index wins (strict '>' scan of the reference)
+    x[4, :] = 1.0
+    out = torch.zeros(B, dtype=torch.int32, device="cuda")
+    K.call("vitk_argmax_rows", dev(x), B, Kc, out, K.stream())
+    o = host(out)
+    np.testing.assert_array_equal(o, x.argmax(1))
+    assert o[3] == 20 and o[4] == 0
+
+
+# ----------------------------------------------------------------------------------- Adam
+def test_adam_vs_oracle_and_golden(K):
+    O = V.oracle()
+    n = 100003
+    p0, m0, v0 = V.rng_normal(1, n), V.rng_normal(2, n) * 0.01, np.abs(V.rng_normal(3, n)) * 1e-4
+    g = V.rng_normal(4, n) * 0.1
+    b1t, b2t = float(np.float32(0.9 ** 3)), float(np.float32(0.999 ** 3))
+    p, m, v = p0.copy(), m0.copy(), v0.copy()
+    O.vo_adam_update(p, g, m, v, n, 3e-4, 0.9, 0.999, b1t, b2t, 1e-8, 1e-4)
+    P, M, Vv = dev(p0), dev(m0), dev(v0)
+    K.call("vitk_adam_l2", P, dev(g), M, Vv, n, 3e-4, 0.9, 0.999, b1t, b2t, 1e-8, 1e-4, 1.0, K.stream())
+    close(host(M), m, 1e-6); close(host(Vv), v, 1e-6)
+    assert np.max(np.abs(host(P) - p)) <= 1e-6 * 3e-4 * 10 + 1e-7 * np.abs(p).max()
+    gd = V.golden("ops.npz")
+    c = V.op_case("adam")
+    r, cc = c["r"], c["c"]
+    P, M, Vv = dev(c["p"]), torch.zeros(r, cc, device="cuda"), torch.zeros(r, cc, device="cuda")
+    for s in range(c["steps"]):
+        b1t = float(np.float32(np.float64(np.float32(0.9)) ** (s + 1)))
+        b2t = float(np.float32(np.float64(np.float32(0.999)) ** (s + 1)))
+        K.call("vitk_adam_l2", P, dev(c["grads"][s]), M, Vv, r * cc, float(c["lrs"][s]), 0.9, 0.999, b1t, b2t, 1e-8,
+               1e-4, 1.0, K.stream())
+    close(host(P), gd["adam_p"], 2e-6)
+
+
+# ------------------------------------------------------------------- embeddings plumbing
+def test_patch_gather_modes(K):
+    O = V.oracle()
+    for (B, Cc, HW, P) in [(3, 1, 28, 14), (2, 3, 28, 7), (2, 3, 32, 16), (1, 3, 224, 16)]:
+        img = V.rng_normal(1, B, Cc, HW, HW)
+        np_ = HW // P
+        pd = P * P * Cc
+        want = V.f32(B * np_ * np_, pd)
+        O.vo_patch_gather(img, B, Cc, HW, P, want)
+        out = empty(B * np_ * np_, pd)
+        K.call("vitk_patch_gather", dev(img), B, Cc, HW, P, K.PATCH_REFERENCE, out, K.stream())
+        np.testing.assert_array_equal(host(out), want)
+        K.call("vitk_patch_gather", dev(img), B, Cc, HW, P, K.PATCH_IM2COL, out, K.stream())
+        true = img.reshape(B, Cc, np_, P, np_, P).transpose(0, 2, 4, 1, 3, 5).reshape(B * np_ * np_, pd)
+        np.testing.assert_array_equal(host(out), true)
+
+
+def test_embed_assemble_split_cls(K):
+    B, Np, D = 5, 16, 48
+    N = Np + 1
+    proj, cls, pos = V.rng_normal(1, B * Np, D), V.rng_normal(2, D), V.rng_normal(3, N, D)
+    out = empty(B, N, D)
+    K.call("vitk_embed_assemble", dev(proj), dev(cls), dev(pos), B, Np, D, out, K.stream())
+    want = np.concatenate([np.broadcast_to(cls, (B, 1, D)), proj.reshape(B, Np, D)], 1) + pos
+    np.testing.assert_array_equal(host(out), want)
+    dy = V.rng_normal(4, B, N, D)
+    dproj = empty(B * Np, D)
+    K.call("vitk_embed_split_bwd", dev(dy), B, Np, D, dproj, K.stream())
+    np.testing.assert_array_equal(host(dproj), dy[:, 1:].reshape(B * Np, D))
+    rows = empty(B, D)
+    K.call("vitk_cls_gather", dev(dy), B, N, D, rows, K.stream())
+    np.testing.assert_array_equal(host(rows), dy[:, 0])
+    back = empty(B, N, D)
+    K.call("vitk_cls_scatter", rows, B, N, D, back, K.stream())
+    want = np.zeros_like(dy)
+    want[:, 0] = dy[:, 0]
+    np.testing.assert_array_equal(host(back), want)
+
+
+def test_dk_reference_scatter(K):
+    B, h, N, dh = 2, 3, 5, 4
+    t = V.rng_normal(1, B * h, dh, N)
+    out = torch.zeros(B * N, h * dh + 2, device="cuda")
+    K.call("vitk_dk_reference_scatter", dev(t), B, h, N, dh, out, h * dh + 2, K.stream())
+    want = t.reshape(B, h, N, dh).transpose(0, 2, 1, 3).reshape(B * N, h * dh)  # [dh][N] bytes re-read as [N][dh]
+    np.testing.assert_array_equal(host(out)[:, :h * dh], want)
+
+
+# ---------------------------------------- attention block composed from the C-ABI calls
+def mha_via_abi(K, c, dk_mode):
+    """q/k/v projection (packed [D][3D] weights), scores, softmax, PV, output projection and the
+    whole backward, exactly as the host layer sequences the kernels."""
+    D, h, B, N = c["D"], c["h"], c["B"], c["N"]
+    dh, M, BH = D // h, B * N, B * h
+    prm = c["prm"]
+    blk = D * D + D
+    Wq, bq = prm[:D * D].reshape(D, D), prm[D * D:blk]
+    Wk, bk = prm[blk:blk + D * D].reshape(D, D), prm[blk + D * D:2 * blk]
+    Wv, bv = prm[2 * blk:2 * blk + D * D].reshape(D, D), prm[2 * blk + D * D:3 * blk]
+    Wo, bo = prm[3 * blk:3 * blk + D * D].reshape(D, D), prm[3 * blk + D * D:]
+    Wqkv, bqkv = dev(np.concatenate([Wq, Wk, Wv], 1)), dev(np.concatenate([bq, bk, bv]))
+    x, dy = dev(c["x"].reshape(M, D)), dev(c["dy"].reshape(M, D))
+    qkv = empty(M, 3 * D)
+    K.gemm(x, Wqkv, qkv, M, 3 * D, D, bias=bqkv)
+    ld = (N + 3) // 4 * 4
+    S = torch.zeros(BH, N, ld, device="cuda")
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(dh)))
+    hs = dict(batch_outer=B, batch_inner=h)
+    tok = (N * 3 * D, dh)
+    K.gemm(qkv, qkv[:, D:], S, N, N, dh, trans_b=True, lda=3 * D, ldb=3 * D, ldc=ld, alpha=scale, stride_a=tok,
+           stride_b=tok, stride_c=(h * N * ld, N * ld), **hs)
+    K.call("vitk_softmax_rows", S, BH * N, N, ld, S, K.stream())
+    ctx = empty(M, D)
+    K.gemm(S, qkv[:, 2 * D:], ctx, N, dh, N, lda=ld, ldb=3 * D, ldc=D, stride_a=(h * N * ld, N * ld), stride_b=tok,
+           stride_c=(N * D, dh), **hs)
+    y = empty(M, D)
+    K.gemm(ctx, dev(Wo), y, M, D, D, bias=dev(bo))
+    # backward
+    dWo, dctx = empty(D, D), empty(M, D)
+    K.gemm(ctx, dy, dWo, D, D, M, trans_a=True, split_k=0)
+    K.gemm(dy, dev(Wo), dctx, M, D, D, trans_b=True)
+    dqkv = torch.zeros(M, 3 * D, device="cuda")
+    dP = torch.zeros(BH, N, ld, device="cuda")
+    K.gemm(dctx, qkv[:, 2 * D:], dP, N, N, dh, trans_b=True, lda=D, ldb=3 * D, ldc=ld, stride_a=(N * D, dh),
+           stride_b=tok, stride_c=(h * N * ld, N * ld), **hs)
+    K.gemm(S, dctx, dqkv[:, 2 * D:], N, dh, N, trans_a=True, lda=ld, ldb=D, ldc=3 * D, stride_a=(h * N * ld, N * ld),
+           stride_b=(N * D, dh), stride_c=tok, **hs)  # dV = P^T dctx
+    K.call("vitk_softmax_rows_bwd", dP, S, BH * N, N, ld, scale, dP, K.stream())  # dS in place
+    K.gemm(dP, qkv[:, D:], dqkv, N, dh, N, lda=ld, ldb=3 * D, ldc=3 * D, stride_a=(h * N * ld, N * ld), stride_b=tok,
+           stride_c=tok, **hs)  # dQ = dS K
+    if dk_mode == K.DK_EXACT:
+        K.gemm(dP, qkv, dqkv[:, D:], N, dh, N, trans_a=True, lda=ld, ldb=3 * D, ldc=3 * D,
+               stride_a=(h * N * ld, N * ld), stride_b=tok, stride_c=tok, **hs)  # dK = dS^T Q
+    else:
+        T = empty(BH, dh, N)
+        K.gemm(qkv, dP, T, dh, N, N, trans_a=True, lda=3 * D, ldb=ld, ldc=N, stride_a=tok,
+               stride_b=(h * N * ld, N * ld), stride_c=(h * dh * N, dh * N), **hs)  # Q^T dS
+        K.call("vitk_dk_reference_scatter", T, B, h, N, dh, dqkv[:, D:], 3 * D, K.stream())
+    dWqkv, dx = empty(D, 3 * D), empty(M, D)
+    K.gemm(x, dqkv, dWqkv, D, 3 * D, M, trans_a=True, split_k=0)
+    K.gemm(dqkv, Wqkv, dx, M, D, 3 * D, trans_b=True)
+    nb = K.dll().vitk_colsum_workspace_bytes(M, 3 * D)
+    ws, dbqkv, dbo = empty(max(nb // 4, 1)), empty(3 * D), empty(D)
+    K.call("vitk_colsum_f32", dqkv, M, 3 * D, 3 * D, dbqkv, ws, nb, K.stream())
+    K.call("vitk_colsum_f32", dy, M, D, D, dbo, ws, nb, K.stream())
+    gW, gb = host(dWqkv), host(dbqkv)
+    grads = np.concatenate([gW[:, :D].ravel(), gb[:D], gW[:, D:2 * D].ravel(), gb[D:2 * D], gW[:, 2 * D:].ravel(),
+                            gb[2 * D:], host(dWo).ravel(), host(dbo)])
+    return host(y).reshape(B, N, D), grads, host(dx).reshape(B, N, D)
+
+
+@pytest.mark.parametrize("tag", ["mha_a", "mha_b"])
+def test_attention_block_matches_reference_golden(K, tag):
+    g = V.golden("ops.npz")
+    c = V.op_case(tag)
+    y, grads, dx = mha_via_abi(K, c, K.DK_REFERENCE)
+    close(y, g[f"{tag}_y"], 2e-5)
+    close(dx, g[f"{tag}_dx"], 2e-5)
+    D = c["D"]
+    blk = D * D + D
+    for i, name in enumerate(("q", "k", "v", "out")):
+        close(grads[i * blk:(i + 1) * blk], g[f"{tag}_g"][i * blk:(i + 1) * blk], 2e-5)
+
+
+def test_attention_exact_key_gradient_differs_only_in_k(K):
+    c = V.op_case("mha_b")
+    y0, g0, dx0 = mha_via_abi(K, c, K.DK_REFERENCE)
+    y1, g1, dx1 = mha_via_abi(K, c, K.DK_EXACT)
+    D = c["D"]
+    blk = D * D + D
+    np.testing.assert_array_equal(y0, y1)
+    np.testing.assert_array_equal(g0[:blk], g1[:blk])          # q
+    np.testing.assert_array_equal(g0[2 * blk:], g1[2 * blk:])  # v, out
+    assert V.max_relerr(g0[blk:2 * blk], g1[blk:2 * blk]) > 1e-2  # the reference's dK is a permutation
+    # exact mode agrees with a float64 autograd of the same attention
+    xt = torch.tensor(c["x"], dtype=torch.float64, requires_grad=True)
+    prm = torch.tensor(c["prm"], dtype=torch.float64)
+    Wk = prm[blk:blk + D * D].reshape(D, D).clone().requires_grad_(True)
+    Wq, bq = prm[:D * D].reshape(D, D), prm[D * D:blk]
+    bk = prm[blk + D * D:2 * blk]
+    Wv, bv = prm[2 * blk:2 * blk + D * D].reshape(D, D), prm[2 * blk + D * D:3 * blk]
+    Wo, bo = prm[3 * blk:3 * blk + D * D].reshape(D, D), prm[3 * blk + D * D:]
+    B, N, h = c["B"], c["N"], c["h"]
+    dh = D // h
+    sp = lambda t: t.reshape(B, N, h, dh).transpose(1, 2)
+    q, k, v = sp(xt @ Wq + bq), sp(xt @ Wk + bk), sp(xt @ Wv + bv)
+    p = torch.softmax(q @ k.transpose(-1, -2) / np.sqrt(dh), -1)
+    out = (p @ v).transpose(1, 2).reshape(B, N, D) @ Wo + bo
+    out.backward(torch.tensor(c["dy"], dtype=torch.float64))
+    close(g1[blk:blk + D * D], Wk.grad.numpy().ravel(), 2e-5)
+    close(dx1, xt.grad.numpy(), 2e-5)

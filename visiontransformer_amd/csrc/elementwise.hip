@@ -1,0 +1,243 @@
+// Single-pass bandwidth kernels: GELU, dropout, adds, scale, fill, strided copy.
+// All are grid-stride, 16 bytes per lane when the buffers allow it (scalar tail / fallback otherwise).
+// Floating-point contraction is off in this file so results match the reference's separately
+// rounded multiply/add sequences.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+template <typename F>
+__global__ void map1_kernel(const float *__restrict__ x, float *__restrict__ y, long long n, bool vec, F f) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (vec) {
+    const long long n4 = n >> 2;
+    for (long long i = tid; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4 *>(x)[i];
+      v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+      reinterpret_cast<float4 *>(y)[i] = v;
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += stride) y[i] = f(x[i]);
+  } else {
+    for (long long i = tid; i < n; i += stride) y[i] = f(x[i]);
+  }
+}
+
+template <typename F>
+__global__ void map2_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y,
+                            long long n, bool vec, F f) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (vec) {
+    const long long n4 = n >> 2;
+    for (long long i = tid; i < n4; i += stride) {
+      const float4 u = reinterpret_cast<const float4 *>(a)[i];
+      const float4 w = reinterpret_cast<const float4 *>(b)[i];
+      float4 v;
+      v.x = f(u.x, w.x); v.y = f(u.y, w.y); v.z = f(u.z, w.z); v.w = f(u.w, w.w);
+      reinterpret_cast<float4 *>(y)[i] = v;
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += stride) y[i] = f(a[i], b[i]);
+  } else {
+    for (long long i = tid; i < n; i += stride) y[i] = f(a[i], b[i]);
+  }
+}
+
+__global__ void add3_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c,
+                            float *__restrict__ y, long long n, bool vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (vec) {
+    const long long n4 = n >> 2;
+    for (long long i = tid; i < n4; i += stride) {
+      const float4 u = reinterpret_cast<const float4 *>(a)[i];
+      const float4 w = reinterpret_cast<const float4 *>(b)[i];
+      const float4 t = reinterpret_cast<const float4 *>(c)[i];
+      float4 v;
+      v.x = (u.x + w.x) + t.x; v.y = (u.y + w.y) + t.y; v.z = (u.z + w.z) + t.z; v.w = (u.w + w.w) + t.w;
+      reinterpret_cast<float4 *>(y)[i] = v;
+    }
+    for (long long i = (n4 << 2) + tid; i < n; i += stride) y[i] = (a[i] + b[i]) + c[i];
+  } else {
+    for (long long i = tid; i < n; i += stride) y[i] = (a[i] + b[i]) + c[i];
+  }
+}
+
+__global__ void fill_kernel(float *__restrict__ x, float value, long long n, bool vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (vec) {
+    const long long n4 = n >> 2;
+    const float4 v = make_float4(value, value, value, value);
+    for (long long i = tid; i < n4; i += stride) reinterpret_cast<float4 *>(x)[i] = v;
+    for (long long i = (n4 << 2) + tid; i < n; i += stride) x[i] = value;
+  } else {
+    for (long long i = tid; i < n; i += stride) x[i] = value;
+  }
+}
+
+__global__ void copy2d_kernel(const float *__restrict__ src, long long lds, float *__restrict__ dst, long long ldd,
+                              long long rows, long long cols, bool vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (vec) {
+    const long long c4 = cols >> 2, total = rows * c4;
+    for (long long i = tid; i < total; i += stride) {
+      const long long r = i / c4, c = (i % c4) << 2;
+      *reinterpret_cast<float4 *>(dst + r * ldd + c) = *reinterpret_cast<const float4 *>(src + r * lds + c);
+    }
+  } else {
+    const long long total = rows * cols;
+    for (long long i = tid; i < total; i += stride) {
+      const long long r = i / cols, c = i % cols;
+      dst[r * ldd + c] = src[r * lds + c];
+    }
+  }
+}
+
+// Philox4x32-10 (Salmon et al.), counter = (ctr_lo, ctr_hi, 0, 0), key = seed.
+__device__ __forceinline__ uint4 philox4x32(unsigned long long ctr, unsigned long long seed) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// One Philox block per group of 4 consecutive elements: element i uses word i%4 of block
+// offset + i/4, so the mask does not depend on the launch geometry.
+__global__ void dropout_fwd_kernel(const float *__restrict__ x, long long n, float rate, float scale,
+                                   unsigned long long seed, unsigned long long offset, float *__restrict__ y,
+                                   float *__restrict__ mask, bool vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long n4 = (n + 3) >> 2;
+  for (long long i = tid; i < n4; i += stride) {
+    const uint4 r = philox4x32(offset + (unsigned long long)i, seed);
+    float m[4];
+    m[0] = u01(r.x) < rate ? 0.f : scale;
+    m[1] = u01(r.y) < rate ? 0.f : scale;
+    m[2] = u01(r.z) < rate ? 0.f : scale;
+    m[3] = u01(r.w) < rate ? 0.f : scale;
+    const long long e = i << 2;
+    if (vec && e + 3 < n) {
+      const float4 v = reinterpret_cast<const float4 *>(x)[i];
+      reinterpret_cast<float4 *>(mask)[i] = make_float4(m[0], m[1], m[2], m[3]);
+      reinterpret_cast<float4 *>(y)[i] = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+    } else {
+      for (int j = 0; j < 4 && e + j < n; ++j) {
+        mask[e + j] = m[j];
+        y[e + j] = x[e + j] * m[j];
+      }
+    }
+  }
+}
+
+struct GeluF { __device__ float operator()(float v) const { return vitk::gelu_fwd(v); } };
+struct GeluB { __device__ float operator()(float x, float dy) const { return vitk::gelu_grad(x) * dy; } };
+struct AddF { __device__ float operator()(float a, float b) const { return a + b; } };
+struct MulF { __device__ float operator()(float a, float b) const { return a * b; } };
+struct ScaleF { float s; __device__ float operator()(float v) const { return v * s; } };
+
+}  // namespace
+
+extern "C" {
+
+int vitk_gelu_fwd(const float *x, int64_t n, float *y, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (x && y)), "vitk_gelu_fwd: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = vitk::aligned16(x) && vitk::aligned16(y);
+  hipLaunchKernelGGL((map1_kernel<GeluF>), dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     x, y, (long long)n, vec, GeluF{});
+  return vitk::check_launch("vitk_gelu_fwd");
+}
+
+int vitk_gelu_bwd(const float *x, const float *dy, int64_t n, float *dx, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (x && dy && dx)), "vitk_gelu_bwd: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = vitk::aligned16(x) && vitk::aligned16(dy) && vitk::aligned16(dx);
+  hipLaunchKernelGGL((map2_kernel<GeluB>), dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     x, dy, dx, (long long)n, vec, GeluB{});
+  return vitk::check_launch("vitk_gelu_bwd");
+}
+
+int vitk_dropout_fwd(const float *x, int64_t n, float rate, uint64_t seed, uint64_t offset, float *y, float *mask,
+                     vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (x && y && mask)), "vitk_dropout_fwd: bad arguments");
+  VITK_REQUIRE(rate >= 0.0f && rate < 1.0f, "vitk_dropout_fwd: rate %g outside [0,1)", (double)rate);
+  if (n == 0) return 0;
+  const float scale = rate > 0.0f ? 1.0f / (1.0f - rate) : 1.0f;
+  const bool vec = vitk::aligned16(x) && vitk::aligned16(y) && vitk::aligned16(mask);
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream), x,
+                     (long long)n, rate, scale, (unsigned long long)seed, (unsigned long long)offset, y, mask, vec);
+  return vitk::check_launch("vitk_dropout_fwd");
+}
+
+int vitk_dropout_bwd(const float *dy, const float *mask, int64_t n, float *dx, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (dy && mask && dx)), "vitk_dropout_bwd: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = vitk::aligned16(dy) && vitk::aligned16(mask) && vitk::aligned16(dx);
+  hipLaunchKernelGGL((map2_kernel<MulF>), dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     dy, mask, dx, (long long)n, vec, MulF{});
+  return vitk::check_launch("vitk_dropout_bwd");
+}
+
+int vitk_add_f32(const float *a, const float *b, int64_t n, float *out, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (a && b && out)), "vitk_add_f32: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = vitk::aligned16(a) && vitk::aligned16(b) && vitk::aligned16(out);
+  hipLaunchKernelGGL((map2_kernel<AddF>), dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     a, b, out, (long long)n, vec, AddF{});
+  return vitk::check_launch("vitk_add_f32");
+}
+
+int vitk_add3_f32(const float *a, const float *b, const float *c, int64_t n, float *out, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (a && b && c && out)), "vitk_add3_f32: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = vitk::aligned16(a) && vitk::aligned16(b) && vitk::aligned16(c) && vitk::aligned16(out);
+  hipLaunchKernelGGL(add3_kernel, dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream), a, b, c,
+                     out, (long long)n, vec);
+  return vitk::check_launch("vitk_add3_f32");
+}
+
+int vitk_scale_f32(const float *x, float s, int64_t n, float *out, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (x && out)), "vitk_scale_f32: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = vitk::aligned16(x) && vitk::aligned16(out);
+  hipLaunchKernelGGL((map1_kernel<ScaleF>), dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     x, out, (long long)n, vec, ScaleF{s});
+  return vitk::check_launch("vitk_scale_f32");
+}
+
+int vitk_fill_f32(float *x, float value, int64_t n, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || x), "vitk_fill_f32: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream), x, value,
+                     (long long)n, vitk::aligned16(x));
+  return vitk::check_launch("vitk_fill_f32");
+}
+
+int vitk_copy2d_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                    vitk_stream_t stream) {
+  VITK_REQUIRE(rows >= 0 && cols >= 0, "vitk_copy2d_f32: negative extent");
+  if (rows == 0 || cols == 0) return 0;
+  VITK_REQUIRE(src && dst && ld_src >= cols && ld_dst >= cols, "vitk_copy2d_f32: bad pointer or pitch");
+  const bool vec = vitk::aligned16(src) && vitk::aligned16(dst) && ld_src % 4 == 0 && ld_dst % 4 == 0 && cols % 4 == 0;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(vitk::grid_for(rows * cols / 4 + 1, TPB)), dim3(TPB), 0,
+                     vitk::as_stream(stream), src, (long long)ld_src, dst, (long long)ld_dst, (long long)rows,
+                     (long long)cols, vec);
+  return vitk::check_launch("vitk_copy2d_f32");
+}
+
+}  // extern "C"

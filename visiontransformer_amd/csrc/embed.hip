@@ -1,0 +1,158 @@
+// Index-shuffling kernels around the embeddings: patch extraction, CLS/positional assembly and
+// its backward split, CLS gather/scatter, and the reference's key-gradient re-read.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__global__ void patch_gather_kernel(const float *__restrict__ img, int B, int C, int HW, int P, int mode,
+                                    float *__restrict__ out) {
+  const int np = HW / P, pd = P * P * C;
+  const long long total = (long long)B * np * np * pd, img_sz = (long long)C * HW * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % pd);
+    const long long pidx = i / pd;
+    const int pw = (int)(pidx % np), ph = (int)((pidx / np) % np);
+    const long long b = pidx / ((long long)np * np);
+    long long src;
+    if (mode == VITK_PATCH_REFERENCE) {
+      src = b * img_sz + (long long)ph * P * HW + (long long)pw * P + j;  // contiguous run
+    } else {
+      const int c = j / (P * P), ii = (j / P) % P, jj = j % P;
+      src = b * img_sz + ((long long)c * HW + ph * P + ii) * HW + pw * P + jj;
+    }
+    out[i] = img[src];
+  }
+}
+
+__global__ void embed_assemble_kernel(const float *__restrict__ proj, const float *__restrict__ cls,
+                                      const float *__restrict__ pos, int B, int Np, int D, float *__restrict__ out) {
+  const int N = Np + 1;
+  const long long total = (long long)B * N * D;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int n = (int)((i / D) % N);
+    const long long b = i / ((long long)D * N);
+    const float base = n == 0 ? cls[d] : proj[(b * Np + (n - 1)) * D + d];
+    out[i] = base + pos[(long long)n * D + d];
+  }
+}
+
+__global__ void embed_split_kernel(const float *__restrict__ dy, int B, int Np, int D, float *__restrict__ dproj) {
+  const int N = Np + 1;
+  const long long total = (long long)B * Np * D;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int p = (int)((i / D) % Np);
+    const long long b = i / ((long long)D * Np);
+    dproj[i] = dy[(b * N + 1 + p) * D + d];
+  }
+}
+
+__global__ void cls_gather_kernel(const float *__restrict__ x, int B, int N, int D, float *__restrict__ out) {
+  const long long total = (long long)B * D;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = x[(i / D) * N * D + (i % D)];
+}
+
+__global__ void cls_scatter_kernel(const float *__restrict__ dcls, int B, int N, int D, float *__restrict__ dx) {
+  const long long total = (long long)B * N * D;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int n = (int)((i / D) % N);
+    dx[i] = n == 0 ? dcls[(i / ((long long)D * N)) * D + d] : 0.f;
+  }
+}
+
+__global__ void dk_scatter_kernel(const float *__restrict__ t, int B, int heads, int N, int dh, float *__restrict__ dk,
+                                  long long ld) {
+  const long long per = (long long)N * dh, total = (long long)B * heads * per;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long bh = i / per, f = i % per;  // f = flat index into the [dh][N] buffer, re-read as [N][dh]
+    const int n = (int)(f / dh), d = (int)(f % dh);
+    const long long b = bh / heads, h = bh % heads;
+    dk[(b * N + n) * ld + h * dh + d] = t[i];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitk_patch_gather(const float *img, int32_t B, int32_t C, int32_t HW, int32_t P, int32_t mode, float *patches,
+                      vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && C > 0 && HW > 0 && P > 0 && HW % P == 0, "vitk_patch_gather: bad geometry (HW=%d P=%d C=%d)",
+               HW, P, C);
+  VITK_REQUIRE(mode == VITK_PATCH_REFERENCE || mode == VITK_PATCH_IM2COL, "vitk_patch_gather: unknown mode %d", mode);
+  if (B == 0) return 0;
+  VITK_REQUIRE(img && patches, "vitk_patch_gather: null pointer");
+  const int np = HW / P;
+  // the contiguous run of the last patch must stay inside its own image
+  VITK_REQUIRE(mode != VITK_PATCH_REFERENCE ||
+                   (long long)(np - 1) * P * HW + (long long)(np - 1) * P + (long long)P * P * C <=
+                       (long long)C * HW * HW,
+               "vitk_patch_gather: reference-mode run of the last patch leaves the image");
+  const long long total = (long long)B * np * np * P * P * C;
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream), img,
+                     B, C, HW, P, mode, patches);
+  return vitk::check_launch("vitk_patch_gather");
+}
+
+int vitk_embed_assemble(const float *proj, const float *cls, const float *pos, int32_t B, int32_t Np, int32_t D,
+                        float *out, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && Np >= 0 && D > 0, "vitk_embed_assemble: bad shape");
+  if (B == 0) return 0;
+  VITK_REQUIRE((proj || Np == 0) && cls && pos && out, "vitk_embed_assemble: null pointer");
+  const long long total = (long long)B * (Np + 1) * D;
+  hipLaunchKernelGGL(embed_assemble_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     proj, cls, pos, B, Np, D, out);
+  return vitk::check_launch("vitk_embed_assemble");
+}
+
+int vitk_embed_split_bwd(const float *dy, int32_t B, int32_t Np, int32_t D, float *dproj, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && Np >= 0 && D > 0, "vitk_embed_split_bwd: bad shape");
+  if (B == 0 || Np == 0) return 0;
+  VITK_REQUIRE(dy && dproj, "vitk_embed_split_bwd: null pointer");
+  const long long total = (long long)B * Np * D;
+  hipLaunchKernelGGL(embed_split_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream), dy, B,
+                     Np, D, dproj);
+  return vitk::check_launch("vitk_embed_split_bwd");
+}
+
+int vitk_cls_gather(const float *x, int32_t B, int32_t N, int32_t D, float *cls_rows, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && N > 0 && D > 0, "vitk_cls_gather: bad shape");
+  if (B == 0) return 0;
+  VITK_REQUIRE(x && cls_rows, "vitk_cls_gather: null pointer");
+  hipLaunchKernelGGL(cls_gather_kernel, dim3(vitk::grid_for((long long)B * D, TPB)), dim3(TPB), 0,
+                     vitk::as_stream(stream), x, B, N, D, cls_rows);
+  return vitk::check_launch("vitk_cls_gather");
+}
+
+int vitk_cls_scatter(const float *dcls, int32_t B, int32_t N, int32_t D, float *dx, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && N > 0 && D > 0, "vitk_cls_scatter: bad shape");
+  if (B == 0) return 0;
+  VITK_REQUIRE(dcls && dx, "vitk_cls_scatter: null pointer");
+  hipLaunchKernelGGL(cls_scatter_kernel, dim3(vitk::grid_for((long long)B * N * D, TPB)), dim3(TPB), 0,
+                     vitk::as_stream(stream), dcls, B, N, D, dx);
+  return vitk::check_launch("vitk_cls_scatter");
+}
+
+int vitk_dk_reference_scatter(const float *t, int32_t B, int32_t heads, int32_t N, int32_t dh, float *dk,
+                              int64_t ld_dk, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && heads > 0 && N > 0 && dh > 0 && ld_dk >= (int64_t)heads * dh, "vitk_dk_reference_scatter: bad shape");
+  if (B == 0) return 0;
+  VITK_REQUIRE(t && dk, "vitk_dk_reference_scatter: null pointer");
+  hipLaunchKernelGGL(dk_scatter_kernel, dim3(vitk::grid_for((long long)B * heads * N * dh, TPB)), dim3(TPB), 0,
+                     vitk::as_stream(stream), t, B, heads, N, dh, dk, (long long)ld_dk);
+  return vitk::check_launch("vitk_dk_reference_scatter");
+}
+
+}  // extern "C"

@@ -1,0 +1,372 @@
+// LayerNorm forward/backward and the two-stage column sum.  Bandwidth kernels: one wave per row,
+// 16-byte loads, wave-level (shuffle) reductions; cross-row reductions (dgamma, dbeta, column
+// sums) go through per-workgroup partials that a second kernel adds in a fixed order.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int WPB = TPB / 64;  // waves (= rows in flight) per workgroup
+
+// ---- forward --------------------------------------------------------------------------------
+// NV = float4 per lane (D <= 256*NV, D % 4 == 0).  NV == 0: generic scalar path for any D.
+template <int NV>
+__global__ __launch_bounds__(TPB) void ln_fwd_kernel(const float *__restrict__ x, long long rows, int D,
+                                                     long long stride, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float eps,
+                                                     float *__restrict__ y, float *__restrict__ mean_out,
+                                                     float *__restrict__ inv_out) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = blockIdx.x * (long long)WPB + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * WPB;
+  for (long long row = wave0; row < rows; row += nwaves) {
+    const float *xr = x + row * stride;
+    float *yr = y + row * stride;
+    if constexpr (NV > 0) {
+      float4 v[NV];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        v[j] = c < D ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      }
+      const float mean = vitk::wave_sum(s) / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+          const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+          q += (a * a + b * b) + (cc * cc + d * d);
+        }
+      }
+      const float var = vitk::wave_sum(q) / (float)D;
+      const float inv = 1.0f / sqrtf(var + eps);
+      if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (inv_out) inv_out[row] = inv;
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+          const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+          const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+          float4 o;
+          o.x = g.x * ((v[j].x - mean) * inv) + b.x;
+          o.y = g.y * ((v[j].y - mean) * inv) + b.y;
+          o.z = g.z * ((v[j].z - mean) * inv) + b.z;
+          o.w = g.w * ((v[j].w - mean) * inv) + b.w;
+          *reinterpret_cast<float4 *>(yr + c) = o;
+        }
+      }
+    } else {
+      float s = 0.f;
+      for (int c = lane; c < D; c += 64) s += xr[c];
+      const float mean = vitk::wave_sum(s) / (float)D;
+      float q = 0.f;
+      for (int c = lane; c < D; c += 64) {
+        const float a = xr[c] - mean;
+        q += a * a;
+      }
+      const float var = vitk::wave_sum(q) / (float)D;
+      const float inv = 1.0f / sqrtf(var + eps);
+      if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (inv_out) inv_out[row] = inv;
+      }
+      for (int c = lane; c < D; c += 64) yr[c] = gamma[c] * ((xr[c] - mean) * inv) + beta[c];
+    }
+  }
+}
+
+// ---- backward -------------------------------------------------------------------------------
+// Per row: dxhat = dy*gamma, s1 = sum dxhat, s2 = sum dxhat*xhat,
+// dx = (1/D)*inv*(D*dxhat - s1 - xhat*s2) (+ residual).  Each lane keeps dgamma/dbeta partials for
+// its own columns over all rows its wave visits; the four waves are combined through LDS and the
+// workgroup writes one [2][D] partial.
+template <int NV>
+__global__ __launch_bounds__(TPB) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                     const float *__restrict__ mean, const float *__restrict__ inv_std,
+                                                     const float *__restrict__ gamma, long long rows, int D,
+                                                     long long stride, const float *__restrict__ residual,
+                                                     float *__restrict__ dx, float *__restrict__ partial) {
+  constexpr int NC = NV > 0 ? NV * 4 : 1;
+  __shared__ float red[2][WPB][NV > 0 ? NV * 256 : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long wave0 = blockIdx.x * (long long)WPB + wv, nwaves = (long long)gridDim.x * WPB;
+  const float fD = (float)D, invD = 1.0f / (float)D;
+  if constexpr (NV > 0) {
+    float dg[NC], db[NC];
+    float4 gm[NV];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) dg[j] = 0.f, db[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      gm[j] = c < D ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long long row = wave0; row < rows; row += nwaves) {
+      const float mu = mean[row], inv = inv_std[row];
+      float4 g[NV], xh[NV];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+          g[j] = *reinterpret_cast<const float4 *>(dy + row * stride + c);
+          const float4 xv = *reinterpret_cast<const float4 *>(x + row * stride + c);
+          xh[j] = make_float4((xv.x - mu) * inv, (xv.y - mu) * inv, (xv.z - mu) * inv, (xv.w - mu) * inv);
+        } else {
+          g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float a = g[j].x * gm[j].x, b = g[j].y * gm[j].y, c2 = g[j].z * gm[j].z, d = g[j].w * gm[j].w;
+        s1 += (a + b) + (c2 + d);
+        s2 += (a * xh[j].x + b * xh[j].y) + (c2 * xh[j].z + d * xh[j].w);
+        dg[4 * j + 0] += g[j].x * xh[j].x; dg[4 * j + 1] += g[j].y * xh[j].y;
+        dg[4 * j + 2] += g[j].z * xh[j].z; dg[4 * j + 3] += g[j].w * xh[j].w;
+        db[4 * j + 0] += g[j].x; db[4 * j + 1] += g[j].y; db[4 * j + 2] += g[j].z; db[4 * j + 3] += g[j].w;
+      }
+      s1 = vitk::wave_sum(s1);
+      s2 = vitk::wave_sum(s2);
+      const float f = invD * inv;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+          float4 o;
+          o.x = f * (fD * (g[j].x * gm[j].x) - s1 - xh[j].x * s2);
+          o.y = f * (fD * (g[j].y * gm[j].y) - s1 - xh[j].y * s2);
+          o.z = f * (fD * (g[j].z * gm[j].z) - s1 - xh[j].z * s2);
+          o.w = f * (fD * (g[j].w * gm[j].w) - s1 - xh[j].w * s2);
+          if (residual) {
+            const float4 r = *reinterpret_cast<const float4 *>(residual + row * stride + c);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+          }
+          *reinterpret_cast<float4 *>(dx + row * stride + c) = o;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[0][wv][(lane + 64 * j) * 4 + e] = dg[4 * j + e];
+        red[1][wv][(lane + 64 * j) * 4 + e] = db[4 * j + e];
+      }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += TPB) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) a += red[0][w][c], b += red[1][w][c];
+      partial[((long long)blockIdx.x * 2 + 0) * D + c] = a;
+      partial[((long long)blockIdx.x * 2 + 1) * D + c] = b;
+    }
+  } else {
+    // generic path: dx only; dgamma/dbeta come from ln_param_grad_generic below
+    for (long long row = wave0; row < rows; row += nwaves) {
+      const float mu = mean[row], inv = inv_std[row];
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = lane; c < D; c += 64) {
+        const float dxh = dy[row * stride + c] * gamma[c], xh = (x[row * stride + c] - mu) * inv;
+        s1 += dxh;
+        s2 += dxh * xh;
+      }
+      s1 = vitk::wave_sum(s1);
+      s2 = vitk::wave_sum(s2);
+      const float f = invD * inv;
+      for (int c = lane; c < D; c += 64) {
+        const float dxh = dy[row * stride + c] * gamma[c], xh = (x[row * stride + c] - mu) * inv;
+        float o = f * (fD * dxh - s1 - xh * s2);
+        if (residual) o += residual[row * stride + c];
+        dx[row * stride + c] = o;
+      }
+    }
+  }
+}
+
+// generic dgamma/dbeta partials: workgroup b handles rows b, b+grid, ...; thread per column.
+__global__ void ln_param_grad_generic(const float *__restrict__ dy, const float *__restrict__ x,
+                                      const float *__restrict__ mean, const float *__restrict__ inv_std,
+                                      long long rows, int D, long long stride, float *__restrict__ partial) {
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+      const float g = dy[row * stride + c];
+      a += g * ((x[row * stride + c] - mean[row]) * inv_std[row]);
+      b += g;
+    }
+    partial[((long long)blockIdx.x * 2 + 0) * D + c] = a;
+    partial[((long long)blockIdx.x * 2 + 1) * D + c] = b;
+  }
+}
+
+__global__ void ln_param_grad_final(const float *__restrict__ partial, int nblk, int D, float *__restrict__ dgamma,
+                                    float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) {
+    a += partial[((long long)k * 2 + 0) * D + c];
+    b += partial[((long long)k * 2 + 1) * D + c];
+  }
+  dgamma[c] = a;
+  dbeta[c] = b;
+}
+
+// ---- column sum -------------------------------------------------------------------------------
+__global__ void colsum_stage1(const float *__restrict__ x, long long rows, long long cols, long long ldx,
+                              long long rows_per_chunk, float *__restrict__ partial) {
+  const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const long long r0 = blockIdx.y * rows_per_chunk;
+  const long long r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += x[r * ldx + c];
+    s1 += x[(r + 1) * ldx + c];
+    s2 += x[(r + 2) * ldx + c];
+    s3 += x[(r + 3) * ldx + c];
+  }
+  for (; r < r1; ++r) s0 += x[r * ldx + c];
+  partial[blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void colsum_stage2(const float *__restrict__ partial, int nchunks, long long cols, float *__restrict__ out) {
+  const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += partial[k * cols + c];
+  out[c] = s;
+}
+
+int ln_blocks(long long rows) {
+  long long b = (rows + WPB - 1) / WPB;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+void colsum_plan(long long rows, long long cols, int *nchunks, long long *rpc) {
+  const long long colblocks = (cols + 255) / 256;
+  long long n = 2048 / colblocks;
+  const long long maxn = (rows + 31) / 32;
+  if (n > maxn) n = maxn;
+  if (n > 1024) n = 1024;
+  if (n < 1) n = 1;
+  *rpc = (rows + n - 1) / n;
+  *nchunks = (int)((rows + *rpc - 1) / *rpc);
+  if (*nchunks < 1) *nchunks = 1;
+}
+
+bool ln_vec_ok(const void *a, const void *b, const void *c, const void *d, long long D, long long stride) {
+  return D % 4 == 0 && D <= 1024 && stride % 4 == 0 && vitk::aligned16(a) && vitk::aligned16(b) &&
+         vitk::aligned16(c) && vitk::aligned16(d);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vitk_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  int n;
+  long long rpc;
+  colsum_plan(rows, cols, &n, &rpc);
+  return (size_t)n * cols * sizeof(float);
+}
+
+int vitk_colsum_f32(const float *x, int64_t rows, int64_t cols, int64_t ldx, float *out, float *workspace,
+                    size_t workspace_bytes, vitk_stream_t stream) {
+  VITK_REQUIRE(rows >= 0 && cols >= 0, "vitk_colsum_f32: negative extent");
+  if (cols == 0) return 0;
+  VITK_REQUIRE(out != nullptr, "vitk_colsum_f32: null output");
+  hipStream_t st = vitk::as_stream(stream);
+  if (rows == 0) return vitk_fill_f32(out, 0.f, cols, stream);
+  VITK_REQUIRE(x != nullptr && ldx >= cols, "vitk_colsum_f32: bad input pointer or pitch");
+  int n;
+  long long rpc;
+  colsum_plan(rows, cols, &n, &rpc);
+  VITK_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)n * cols * sizeof(float),
+               "vitk_colsum_f32: workspace too small (%zu < %zu)", workspace_bytes, (size_t)n * cols * sizeof(float));
+  VITK_REQUIRE(n <= 65535, "vitk_colsum_f32: too many row chunks");
+  const unsigned cb = (unsigned)((cols + 255) / 256);
+  hipLaunchKernelGGL(colsum_stage1, dim3(cb, (unsigned)n), dim3(256), 0, st, x, (long long)rows, (long long)cols,
+                     (long long)ldx, rpc, workspace);
+  if (vitk::check_launch("vitk_colsum_f32/stage1")) return 1;
+  hipLaunchKernelGGL(colsum_stage2, dim3(cb), dim3(256), 0, st, workspace, n, (long long)cols, out);
+  return vitk::check_launch("vitk_colsum_f32/stage2");
+}
+
+int vitk_layernorm_fwd(const float *x, int64_t rows, int64_t D, int64_t row_stride, const float *gamma,
+                       const float *beta, float eps, float *y, float *mean, float *inv_std, vitk_stream_t stream) {
+  VITK_REQUIRE(rows >= 0 && D > 0 && row_stride >= D, "vitk_layernorm_fwd: bad shape (rows=%lld D=%lld stride=%lld)",
+               (long long)rows, (long long)D, (long long)row_stride);
+  if (rows == 0) return 0;
+  VITK_REQUIRE(x && y && gamma && beta, "vitk_layernorm_fwd: null pointer");
+  VITK_REQUIRE(D < (1ll << 30), "vitk_layernorm_fwd: D too large");
+  hipStream_t st = vitk::as_stream(stream);
+  const dim3 g2((unsigned)vitk::grid_for(rows, WPB)), blk(TPB);
+  const bool vec = ln_vec_ok(x, y, gamma, beta, D, row_stride);
+  const int nv = vec ? (int)((D + 255) / 256) : 0;
+#define LNF(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV>), g2, blk, 0, st, x, (long long)rows, (int)D, \
+                                   (long long)row_stride, gamma, beta, eps, y, mean, inv_std)
+  switch (nv) {
+    case 1: LNF(1); break;
+    case 2: LNF(2); break;
+    case 3: LNF(3); break;
+    case 4: LNF(4); break;
+    default: LNF(0); break;
+  }
+#undef LNF
+  return vitk::check_launch("vitk_layernorm_fwd");
+}
+
+size_t vitk_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) {
+  if (rows <= 0 || D <= 0) return 0;
+  return (size_t)ln_blocks(rows) * 2 * D * sizeof(float);
+}
+
+int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *inv_std, const float *gamma,
+                       int64_t rows, int64_t D, int64_t row_stride, const float *residual, float *dx, float *dgamma,
+                       float *dbeta, float *workspace, size_t workspace_bytes, vitk_stream_t stream) {
+  VITK_REQUIRE(rows >= 0 && D > 0 && row_stride >= D, "vitk_layernorm_bwd: bad shape");
+  VITK_REQUIRE(dgamma && dbeta, "vitk_layernorm_bwd: null parameter-gradient pointer");
+  if (rows == 0) {
+    if (vitk_fill_f32(dgamma, 0.f, D, stream)) return 1;
+    return vitk_fill_f32(dbeta, 0.f, D, stream);
+  }
+  VITK_REQUIRE(dy && x && mean && inv_std && gamma && dx, "vitk_layernorm_bwd: null pointer");
+  const int nblk = ln_blocks(rows);
+  const size_t need = (size_t)nblk * 2 * D * sizeof(float);
+  VITK_REQUIRE(workspace && workspace_bytes >= need, "vitk_layernorm_bwd: workspace too small (%zu < %zu)",
+               workspace_bytes, need);
+  hipStream_t st = vitk::as_stream(stream);
+  const dim3 grid(nblk), blk(TPB);
+  const bool vec = ln_vec_ok(dy, x, gamma, dx, D, row_stride) && (residual == nullptr || vitk::aligned16(residual));
+  const int nv = vec ? (int)((D + 255) / 256) : 0;
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, blk, 0, st, dy, x, mean, inv_std, gamma, \
+                                   (long long)rows, (int)D, (long long)row_stride, residual, dx, workspace)
+  switch (nv) {
+    case 1: LNB(1); break;
+    case 2: LNB(2); break;
+    case 3: LNB(3); break;
+    case 4: LNB(4); break;
+    default:
+      LNB(0);
+      if (vitk::check_launch("vitk_layernorm_bwd/dx")) return 1;
+      hipLaunchKernelGGL(ln_param_grad_generic, grid, blk, 0, st, dy, x, mean, inv_std, (long long)rows, (int)D,
+                         (long long)row_stride, workspace);
+      break;
+  }
+#undef LNB
+  if (vitk::check_launch("vitk_layernorm_bwd")) return 1;
+  hipLaunchKernelGGL(ln_param_grad_final, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, workspace, nblk, (int)D,
+                     dgamma, dbeta);
+  return vitk::check_launch("vitk_layernorm_bwd/final");
+}
+
+}  // extern "C"

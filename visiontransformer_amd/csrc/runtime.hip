@@ -1,0 +1,49 @@
+// Library-level entry points of include/vitk.h: version, error string, device selection.
+#include "common.h"
+
+#include <cstring>
+
+namespace vitk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+}  // namespace vitk
+
+extern "C" {
+
+int vitk_version(void) { return 100; }
+
+const char *vitk_last_error(void) { return vitk::g_err; }
+
+int vitk_init(int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  VITK_REQUIRE(e == hipSuccess && count > 0, "vitk_init: no HIP device visible (%s)", hipGetErrorString(e));
+  VITK_REQUIRE(device >= 0 && device < count, "vitk_init: device %d out of range [0,%d)", device, count);
+  e = hipSetDevice(device);
+  VITK_REQUIRE(e == hipSuccess, "vitk_init: hipSetDevice(%d): %s", device, hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  VITK_REQUIRE(e == hipSuccess, "vitk_init: hipGetDeviceProperties: %s", hipGetErrorString(e));
+  VITK_REQUIRE(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+               "vitk_init: device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
+  return 0;
+}
+
+}  // extern "C"
