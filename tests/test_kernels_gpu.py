@@ -26,7 +26,9 @@ def K():
 
 
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a = np.ascontiguousarray(a)
+    assert a.dtype in (np.float32, np.int32), a.dtype
+    return torch.from_numpy(a).cuda()
 
 
 def host(t):
@@ -56,7 +58,7 @@ def test_gemm_layout_identity_with_asymmetric_b(K):
     # A = I, B asymmetric: catches a transposed accumulator map or swapped operands exactly
     n = 96
     a = np.eye(n, dtype=np.float32)
-    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251) - 17 * (np.arange(n)[:, None] % 3)
+    b = ((np.arange(n * n).reshape(n, n) % 251) - 17 * (np.arange(n)[:, None] % 3)).astype(np.float32)
     c = empty(n, n)
     K.gemm(dev(a), dev(b), c, n, n, n)
     np.testing.assert_array_equal(host(c), b)

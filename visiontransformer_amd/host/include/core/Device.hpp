@@ -1,0 +1,52 @@
+// Device runtime of the host layer: one HIP stream, a caching device allocator and a grow-only
+// scratch workspace.  Everything the Tensor / Layer classes enqueue goes through here, so a
+// steady-state training step performs no hipMalloc/hipFree.
+#ifndef VIT_DEVICE_HPP
+#define VIT_DEVICE_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace vit {
+
+// Throws std::runtime_error(vitk_last_error()) when a libvitk call failed (the reference's error
+// convention is C++ exceptions caught once in main, app/main.cpp:76-79).
+void check(int rc, const char *what);
+void hip_check(int hip_error, const char *what);
+
+// Select the device (default 0) -- called implicitly on first use.
+void init(int device = 0);
+// Use an existing hipStream_t (e.g. the caller framework's current stream) instead of the
+// library's own; nullptr selects the default (null) stream.
+void set_stream(void *hip_stream);
+void *stream();
+void synchronize();
+
+// Caching allocator: freed blocks are kept per size and reused; safe because every consumer is
+// ordered on the one stream above.
+float *device_alloc(size_t count);
+void device_free(float *p, size_t count);
+void release_cached_memory();
+size_t device_bytes_in_use();
+
+// Grow-only scratch for split-K partials, column-sum and LayerNorm partials.
+float *workspace(size_t bytes);
+size_t workspace_bytes();
+
+void copy_to_device(float *dst, const float *src, size_t count);
+void copy_to_host(float *dst, const float *src, size_t count);  // synchronises
+void copy_on_device(float *dst, const float *src, size_t count);
+void zero_device(float *dst, size_t count);
+
+// Reproducible host RNG for weight init / shuffles (the reference seeds from random_device; call
+// seed() to make runs repeatable).
+void seed(uint64_t s);
+uint64_t next_seed();
+// (seed, offset) pair for the next dropout mask of `count` elements.
+void dropout_stream(size_t count, uint64_t *seed_out, uint64_t *offset_out);
+
+}  // namespace vit
+
+#endif

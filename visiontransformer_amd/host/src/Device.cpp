@@ -1,0 +1,176 @@
+#include "core/Device.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <random>
+#include <unordered_map>
+#include <vector>
+
+#include "vitk.h"
+
+namespace vit {
+
+namespace {
+
+struct State {
+  bool initialised = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::unordered_map<size_t, std::vector<void *>> free_lists;
+  size_t in_use = 0, cached = 0;
+  void *ws = nullptr;
+  size_t ws_bytes = 0;
+  std::mt19937_64 rng{std::random_device{}()};
+  uint64_t dropout_seed = 0x5eedULL;
+  uint64_t dropout_offset = 0;
+};
+
+State &S() {
+  static State s;
+  return s;
+}
+
+size_t round_up(size_t bytes) { return (bytes + 255) / 256 * 256; }
+
+}  // namespace
+
+void check(int rc, const char *what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + ": " + vitk_last_error());
+}
+
+void hip_check(int e, const char *what) {
+  if (e != hipSuccess)
+    throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(static_cast<hipError_t>(e)));
+}
+
+void init(int device) {
+  State &s = S();
+  if (s.initialised && s.device == device) return;
+  check(vitk_init(device), "vitk_init");
+  s.device = device;
+  s.initialised = true;
+}
+
+static void ensure() {
+  if (!S().initialised) init(0);
+}
+
+void set_stream(void *hip_stream) {
+  ensure();
+  S().stream = static_cast<hipStream_t>(hip_stream);
+}
+
+void *stream() {
+  ensure();
+  return S().stream;
+}
+
+void synchronize() {
+  ensure();
+  hip_check(hipStreamSynchronize(S().stream), "hipStreamSynchronize");
+}
+
+float *device_alloc(size_t count) {
+  ensure();
+  State &s = S();
+  const size_t bytes = round_up((count ? count : 1) * sizeof(float));
+  auto it = s.free_lists.find(bytes);
+  void *p = nullptr;
+  if (it != s.free_lists.end() && !it->second.empty()) {
+    p = it->second.back();
+    it->second.pop_back();
+    s.cached -= bytes;
+  } else {
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      release_cached_memory();
+      hip_check(hipMalloc(&p, bytes), "hipMalloc");
+    }
+  }
+  s.in_use += bytes;
+  return static_cast<float *>(p);
+}
+
+void device_free(float *p, size_t count) {
+  if (!p) return;
+  State &s = S();
+  const size_t bytes = round_up((count ? count : 1) * sizeof(float));
+  s.free_lists[bytes].push_back(p);
+  s.in_use -= bytes;
+  s.cached += bytes;
+}
+
+void release_cached_memory() {
+  State &s = S();
+  if (s.cached == 0) return;
+  (void)hipStreamSynchronize(s.stream);
+  for (auto &kv : s.free_lists) {
+    for (void *p : kv.second) (void)hipFree(p);
+    kv.second.clear();
+  }
+  s.cached = 0;
+}
+
+size_t device_bytes_in_use() { return S().in_use; }
+
+float *workspace(size_t bytes) {
+  ensure();
+  State &s = S();
+  if (bytes > s.ws_bytes) {
+    if (s.ws) {
+      (void)hipStreamSynchronize(s.stream);
+      (void)hipFree(s.ws);
+      s.ws = nullptr;
+    }
+    const size_t want = round_up(bytes + bytes / 4);
+    hip_check(hipMalloc(&s.ws, want), "hipMalloc(workspace)");
+    s.ws_bytes = want;
+  }
+  return static_cast<float *>(s.ws);
+}
+
+size_t workspace_bytes() { return S().ws_bytes; }
+
+void copy_to_device(float *dst, const float *src, size_t count) {
+  ensure();
+  if (!count) return;
+  // pageable source: hipMemcpyAsync returns after staging, so the host buffer may be reused
+  hip_check(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyHostToDevice, S().stream), "H2D copy");
+  hip_check(hipStreamSynchronize(S().stream), "H2D sync");
+}
+
+void copy_to_host(float *dst, const float *src, size_t count) {
+  ensure();
+  if (!count) return;
+  hip_check(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, S().stream), "D2H copy");
+  hip_check(hipStreamSynchronize(S().stream), "D2H sync");
+}
+
+void copy_on_device(float *dst, const float *src, size_t count) {
+  ensure();
+  if (!count) return;
+  hip_check(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToDevice, S().stream), "D2D copy");
+}
+
+void zero_device(float *dst, size_t count) {
+  ensure();
+  if (!count) return;
+  hip_check(hipMemsetAsync(dst, 0, count * sizeof(float), S().stream), "memset");
+}
+
+void seed(uint64_t s) {
+  S().rng.seed(s);
+  S().dropout_seed = s * 0x9E3779B97F4A7C15ULL + 0x5eedULL;
+  S().dropout_offset = 0;
+}
+
+uint64_t next_seed() { return S().rng(); }
+
+void dropout_stream(size_t count, uint64_t *seed_out, uint64_t *offset_out) {
+  State &s = S();
+  *seed_out = s.dropout_seed;
+  *offset_out = s.dropout_offset;
+  s.dropout_offset += (count + 3) / 4;
+}
+
+}  // namespace vit
