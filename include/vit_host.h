@@ -1,0 +1,124 @@
+/*
+ * vit_host.h -- C-ABI of libvit_host.so: the C++ host layer (Tensor / Layer / Loss / Optimizer /
+ * Trainer / ModelUtils classes with the reference's API, visiontransformer_amd/host/) driven
+ * through opaque handles, for callers that are not C++ (tests, bench.py, the data-parallel
+ * driver).  A C++ application uses the classes directly, exactly as app/main.cpp of the
+ * reference does.
+ *
+ * Every function returns 0 on success (or a value, where documented) and non-zero on failure;
+ * vith_last_error() returns the message of the calling thread's last failure (the C++
+ * exception text).  Pointers named *_dev are device pointers, *_host host pointers.  All work is
+ * enqueued on the stream set with vith_set_stream (default: the null stream); functions that
+ * return values to the host synchronise that stream.
+ */
+#ifndef VIT_HOST_H
+#define VIT_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ViTConfig (include/model/VisionTransformer.hpp:19-29 of the reference), field for field. */
+typedef struct vith_config {
+  uint64_t image_size, patch_size, in_channels, num_classes, embedding_dim, num_heads, num_layers, mlp_hidden_dim;
+  float dropout_rate;
+} vith_config;
+
+typedef void *vith_model;   /* VisionTransformer */
+typedef void *vith_trainer; /* CrossEntropy + Adam + schedule state around one model */
+
+const char *vith_last_error(void);
+int vith_init(int device);
+int vith_set_stream(void *hip_stream);
+int vith_synchronize(void);
+/* seeds weight initialisation, data subsampling and dropout (the reference uses random_device) */
+int vith_seed(uint64_t seed);
+uint64_t vith_device_bytes_in_use(void);
+
+/* ---- model: VisionTransformer (src/model/VisionTransformer.cpp of the reference) ------------ */
+/* patch_mode: VITK_PATCH_REFERENCE (0) / VITK_PATCH_IM2COL (1); dk_mode: VITK_DK_REFERENCE (0) /
+ * VITK_DK_EXACT (1) -- see include/vitk.h. */
+vith_model vith_model_create(const vith_config *cfg, int patch_mode, int dk_mode);
+void vith_model_destroy(vith_model m);
+uint64_t vith_param_count(vith_model m);
+uint64_t vith_param_tensors(vith_model m);
+/* shape of parameter tensor idx in getParameters() order; dims holds 4 entries; returns the rank */
+uint64_t vith_param_shape(vith_model m, uint64_t idx, uint64_t *dims);
+/* flat copies in getParameters()/getGradients() order, every tensor contiguous (= the payload
+ * order of a .weights file) */
+int vith_get_params(vith_model m, float *flat_host);
+int vith_set_params(vith_model m, const float *flat_host);
+int vith_get_grads(vith_model m, float *flat_host);
+/* device arenas (device layout: q/k/v weights of a layer packed as one {D,3D} block); both hold
+ * vith_param_count() floats; for collectives and optimiser kernels, which are layout-agnostic */
+float *vith_params_device(vith_model m);
+float *vith_grads_device(vith_model m);
+/* ModelUtils::{save,load}_weights / {save,load}_config (src/utils/ModelUtils.cpp) */
+int vith_save_weights(vith_model m, const char *path);
+int vith_load_weights(vith_model m, const char *path);
+int vith_save_config(const vith_config *cfg, const char *path);
+int vith_load_config(const char *path, vith_config *cfg);
+
+/* forward: x_dev {B,C,H,W} -> logits_dev {B,K} (VisionTransformer::forward) */
+int vith_forward(vith_model m, const float *x_dev, uint64_t B, int training, float *logits_dev);
+/* forward in training mode that also copies the token stream after the embeddings, after every
+ * block and after the final norm into acts_dev ((L+2) x {B,N,D}) */
+int vith_forward_trace(vith_model m, const float *x_dev, uint64_t B, float *acts_dev, float *logits_dev);
+/* backward from dlogits_dev {B,K} (VisionTransformer::backward); dacts_dev (optional) receives
+ * (L+1) x {B,N,D}: gradient w.r.t. the final-norm input, then each block's input, last block first */
+int vith_backward(vith_model m, const float *dlogits_dev, uint64_t B, float *dacts_dev);
+/* top-1: first index of the row maximum of softmax(logits) (app/test.cpp:92-112) */
+int vith_predict(vith_model m, const float *x_dev, uint64_t B, int32_t *pred_dev);
+
+/* ---- trainer: the per-batch body of Trainer::train_epoch (src/model/Trainer.cpp:201-227) ---- */
+vith_trainer vith_trainer_create(vith_model m, float beta1, float beta2, float eps, float weight_decay,
+                                 const float *class_weights_host, uint64_t n_weights);
+void vith_trainer_destroy(vith_trainer t);
+/* one whole step on one device: forward, loss, backward, Adam(lr).  loss/correct may be NULL. */
+int vith_train_step(vith_trainer t, const float *x_dev, const float *y_onehot_dev, uint64_t B, float lr,
+                    float *loss_host, float *correct_host);
+/* the same step in pieces, for gradient all-reduce overlapped with backward:
+ *   vith_step_forward  : forward + fused softmax-CE; gradient divided by grad_batch (the GLOBAL
+ *                        batch under data parallelism; 0 = B).  Does not synchronise.
+ *   vith_step_backward_stage(s), s = 0 .. vith_num_stages-1: head+final norm, blocks last to
+ *                        first, embeddings.  After stage s the slice
+ *                        [offset, offset+count) of the gradient arena given by
+ *                        vith_stage_grad_range is final and may be reduced.
+ *   vith_step_update   : Adam(lr) over the whole arena; gradients are multiplied by grad_scale.
+ *   vith_step_result   : {mean loss of the local batch, number of correct rows} (synchronises). */
+int vith_step_forward(vith_trainer t, const float *x_dev, const float *y_onehot_dev, uint64_t B, float grad_batch);
+uint64_t vith_num_stages(vith_trainer t);
+int vith_step_backward_stage(vith_trainer t, uint64_t stage);
+int vith_stage_grad_range(vith_trainer t, uint64_t stage, uint64_t *offset, uint64_t *count);
+int vith_step_update(vith_trainer t, float lr, float grad_scale);
+int vith_step_result(vith_trainer t, float *loss_host, float *correct_host);
+/* evaluation of one batch in inference mode: loss and number of correct rows */
+int vith_eval_batch(vith_trainer t, const float *x_dev, const float *y_onehot_dev, uint64_t B, float *loss_host,
+                    float *correct_host);
+/* cosine_warmup_lr (include/optimizers/Scheduler.hpp:5-16) */
+float vith_cosine_warmup_lr(int64_t step, int64_t warmup_steps, int64_t total_steps, float lr_max);
+/* sample order of epoch `epoch` in Trainer::train_epoch: iota(n) shuffled by mt19937(epoch) */
+int vith_epoch_order(uint64_t n, int32_t epoch, uint64_t *order_host);
+
+/* ---- single layers (each a reference Layer subclass), for op-level parity tests ------------- */
+/* kind: 0 Dense(a=in,b=out) 1 LayerNorm(a=D) 2 GELU 3 MultiHeadAttention(a=D,b=heads)
+ *       4 FeedForward(a=D,b=H) 5 TransformerEncoderBlock(a=D,b=heads,c=H)
+ *       6 Embeddings(a=image,b=patch,c=channels,d=D) */
+typedef void *vith_layer;
+vith_layer vith_layer_create(int kind, uint64_t a, uint64_t b, uint64_t c, uint64_t d);
+void vith_layer_destroy(vith_layer l);
+uint64_t vith_layer_param_count(vith_layer l);
+int vith_layer_set_params(vith_layer l, const float *flat_host);
+int vith_layer_get_grads(vith_layer l, float *flat_host);
+/* x_host has x_rank dims in x_shape; y_host receives the output (y_count floats are expected) */
+int vith_layer_forward(vith_layer l, const float *x_host, const uint64_t *x_shape, uint64_t x_rank, int training,
+                       float *y_host, uint64_t y_count);
+int vith_layer_backward(vith_layer l, const float *dy_host, const uint64_t *dy_shape, uint64_t dy_rank,
+                        float *dx_host, uint64_t dx_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_HOST_H */

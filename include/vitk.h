@@ -130,9 +130,17 @@ int vitk_add_f32(const float *a, const float *b, int64_t n, float *out, vitk_str
 int vitk_add3_f32(const float *a, const float *b, const float *c, int64_t n, float *out, vitk_stream_t stream);
 int vitk_scale_f32(const float *x, float s, int64_t n, float *out, vitk_stream_t stream);
 int vitk_fill_f32(float *x, float value, int64_t n, vitk_stream_t stream);
+/* x[r][c] += v[c] in place: Tensor::addBroadcast ({1,N} over {M,N} and {1,N,D} over {B,N,D},
+ * src/core/Tensor.cpp:435-461) outside a GEMM epilogue. */
+int vitk_add_rowvec_f32(float *x, int64_t rows, int64_t cols, const float *v, vitk_stream_t stream);
 /* strided 2-D copy: dst[r][c] = src[r][c], r < rows, c < cols (contiguous()/slice copies,
  * src/core/Tensor.cpp:227-254). */
 int vitk_copy2d_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                    vitk_stream_t stream);
+/* gather of a strided view of up to 4 dimensions (shape4/strides4 in elements, host arrays of 4;
+ * pad leading dimensions with extent 1) into a contiguous buffer: the general form of
+ * Tensor::contiguous() for transposed / sliced / stride-0 expanded views. */
+int vitk_copy4d_f32(const float *src, const int64_t *shape4, const int64_t *strides4, float *dst,
                     vitk_stream_t stream);
 
 /* ---- row softmax over the last axis and its backward (src/layers/MultiHeadAttention.cpp:123-156

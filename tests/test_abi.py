@@ -39,3 +39,56 @@ def test_vitk_argument_validation_reports_errors():
     with pytest.raises(vitk.VitkError):
         vitk.call("vitk_dropout_fwd", None, 4, 1.5, 0, 0, None, None, None)
     assert C.sizeof(vitk.GemmArgs) == 200
+
+
+def test_vit_host_exports_every_declared_symbol():
+    from visiontransformer_amd import host
+    names = declared("vit_host.h", "vith_")
+    assert len(names) >= 40
+    d = host.dll()
+    for n in names:
+        assert hasattr(d, n), f"libvit_host.so does not export {n}"
+        assert n in host.SIGNATURES, f"no ctypes signature for {n}"
+    assert sorted(host.SIGNATURES) == names
+    # pure-host entry points work without a GPU
+    assert host.cosine_warmup_lr(0, 10, 100, 3e-4) == 0.0
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import vitlibs as V
+    g = V.golden("ops.npz")
+    import numpy as np
+    sched = np.array([host.cosine_warmup_lr(s, 10, 100, 3e-4) for s in range(100)], dtype=np.float32)
+    np.testing.assert_array_equal(sched, g["sched"])  # bit-identical learning rates
+    for ep in (0, 1, 7):
+        np.testing.assert_array_equal(host.epoch_order(50, ep), g[f"order_{ep}"])  # Trainer's per-epoch order
+
+
+def test_config_json_round_trip_matches_reference_file(tmp_path):
+    from visiontransformer_amd import host
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import vitlibs as V
+    ref_json = os.path.join(V.GOLDEN, "vit_mnist_4_8.json")
+    cfg = host.load_config(ref_json)
+    assert cfg.as_dict() == dict(V.CONFIGS["CK"], dropout_rate=0.0)
+    out = tmp_path / "c.json"
+    host.save_config(cfg, str(out))
+    # same content as the shipped file (which an older writer indented by 2) ...
+    assert out.read_text().split() == open(ref_json).read().split()
+    # ... and the same BYTES as the reference's current writer (4-space indent), where it is built
+    R = V.ref()
+    if R is not None:
+        rcfg = V.Cfg.make(**V.CONFIGS["CK"])
+        ref_out = tmp_path / "r.json"
+        assert R.vref_save_config(rcfg, str(ref_out).encode()) == 0
+        assert out.read_bytes() == ref_out.read_bytes()
+        rcfg = V.Cfg.make(**V.CONFIGS["C1"], dropout_rate=0.2)
+        assert R.vref_save_config(rcfg, str(ref_out).encode()) == 0
+        host.save_config(host.Config.make(**V.CONFIGS["C1"], dropout_rate=0.2), str(out))
+        assert out.read_bytes() == ref_out.read_bytes()
+    cfg2 = host.Config.make(**V.CONFIGS["C1"], dropout_rate=0.2)
+    host.save_config(cfg2, str(out))
+    back = host.load_config(str(out))
+    assert back.as_dict() == cfg2.as_dict()
+    with pytest.raises(host.HostError):
+        host.load_config(str(tmp_path / "missing.json"))

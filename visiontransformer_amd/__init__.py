@@ -12,4 +12,4 @@ data-parallel driver; PyTorch supplies device memory, streams and ``torch.distri
 There is no CPU fallback: importing works anywhere, calling a kernel without the built
 libraries or without a GPU raises.
 """
-from . import vitk  # noqa: F401
+from . import host, vitk  # noqa: F401

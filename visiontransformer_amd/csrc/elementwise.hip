@@ -98,6 +98,24 @@ __global__ void copy2d_kernel(const float *__restrict__ src, long long lds, floa
   }
 }
 
+// Generic strided gather of a view with up to 4 dimensions into a contiguous buffer.
+struct Dims4 { long long shape[4]; long long stride[4]; };
+__global__ void copy4d_kernel(const float *__restrict__ src, Dims4 d, float *__restrict__ dst, long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long r = i;
+    const long long i3 = r % d.shape[3]; r /= d.shape[3];
+    const long long i2 = r % d.shape[2]; r /= d.shape[2];
+    const long long i1 = r % d.shape[1]; r /= d.shape[1];
+    dst[i] = src[r * d.stride[0] + i1 * d.stride[1] + i2 * d.stride[2] + i3 * d.stride[3]];
+  }
+}
+
+__global__ void add_rowvec_kernel(float *__restrict__ x, long long rows, long long cols, const float *__restrict__ v) {
+  const long long total = rows * cols, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += stride) x[i] += v[i % cols];
+}
+
 // Philox4x32-10 (Salmon et al.), counter = (ctr_lo, ctr_hi, 0, 0), key = seed.
 __device__ __forceinline__ uint4 philox4x32(unsigned long long ctr, unsigned long long seed) {
   unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
@@ -238,6 +256,33 @@ int vitk_copy2d_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst
                      vitk::as_stream(stream), src, (long long)ld_src, dst, (long long)ld_dst, (long long)rows,
                      (long long)cols, vec);
   return vitk::check_launch("vitk_copy2d_f32");
+}
+
+int vitk_copy4d_f32(const float *src, const int64_t *shape4, const int64_t *strides4, float *dst,
+                    vitk_stream_t stream) {
+  VITK_REQUIRE(shape4 && strides4, "vitk_copy4d_f32: null shape/strides");
+  Dims4 d;
+  long long total = 1;
+  for (int i = 0; i < 4; ++i) {
+    VITK_REQUIRE(shape4[i] >= 0 && strides4[i] >= 0, "vitk_copy4d_f32: negative extent or stride");
+    d.shape[i] = shape4[i];
+    d.stride[i] = strides4[i];
+    total *= shape4[i];
+  }
+  if (total == 0) return 0;
+  VITK_REQUIRE(src && dst, "vitk_copy4d_f32: null pointer");
+  hipLaunchKernelGGL(copy4d_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream), src, d, dst,
+                     total);
+  return vitk::check_launch("vitk_copy4d_f32");
+}
+
+int vitk_add_rowvec_f32(float *x, int64_t rows, int64_t cols, const float *v, vitk_stream_t stream) {
+  VITK_REQUIRE(rows >= 0 && cols >= 0, "vitk_add_rowvec_f32: negative extent");
+  if (rows == 0 || cols == 0) return 0;
+  VITK_REQUIRE(x && v, "vitk_add_rowvec_f32: null pointer");
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(vitk::grid_for(rows * cols, TPB)), dim3(TPB), 0, vitk::as_stream(stream), x,
+                     (long long)rows, (long long)cols, v);
+  return vitk::check_launch("vitk_add_rowvec_f32");
 }
 
 }  // extern "C"

@@ -1,0 +1,338 @@
+"""ctypes binding of include/vit_host.h (lib/libvit_host.so): the C++ host layer -- the
+reference-API Tensor / Layer / Loss / Optimizer / Trainer / ModelUtils classes -- behind opaque
+handles.  Device pointers come from torch CUDA tensors."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import vitk
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvit_host.so")
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("image_size", "patch_size", "in_channels", "num_classes", "embedding_dim",
+                                          "num_heads", "num_layers", "mlp_hidden_dim")] + [("dropout_rate", C.c_float)]
+
+    @classmethod
+    def make(cls, image_size, patch_size, in_channels, num_classes, embedding_dim, num_heads, num_layers,
+             mlp_hidden_dim, dropout_rate=0.0):
+        return cls(image_size, patch_size, in_channels, num_classes, embedding_dim, num_heads, num_layers,
+                   mlp_hidden_dim, dropout_rate)
+
+    @property
+    def tokens(self):
+        return 1 + (self.image_size // self.patch_size) ** 2
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_[:-1]}
+        d["dropout_rate"] = float(self.dropout_rate)
+        return d
+
+
+_p, _u64, _i64, _i32, _f, _int = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_float, C.c_int
+_pf, _pu = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+
+SIGNATURES = {
+    "vith_last_error": (C.c_char_p, []),
+    "vith_init": (_int, [_int]),
+    "vith_set_stream": (_int, [_p]),
+    "vith_synchronize": (_int, []),
+    "vith_seed": (_int, [_u64]),
+    "vith_device_bytes_in_use": (_u64, []),
+    "vith_model_create": (_p, [C.POINTER(Config), _int, _int]),
+    "vith_model_destroy": (None, [_p]),
+    "vith_param_count": (_u64, [_p]),
+    "vith_param_tensors": (_u64, [_p]),
+    "vith_param_shape": (_u64, [_p, _u64, _pu]),
+    "vith_get_params": (_int, [_p, _p]),
+    "vith_set_params": (_int, [_p, _p]),
+    "vith_get_grads": (_int, [_p, _p]),
+    "vith_params_device": (_p, [_p]),
+    "vith_grads_device": (_p, [_p]),
+    "vith_save_weights": (_int, [_p, C.c_char_p]),
+    "vith_load_weights": (_int, [_p, C.c_char_p]),
+    "vith_save_config": (_int, [C.POINTER(Config), C.c_char_p]),
+    "vith_load_config": (_int, [C.c_char_p, C.POINTER(Config)]),
+    "vith_forward": (_int, [_p, _p, _u64, _int, _p]),
+    "vith_forward_trace": (_int, [_p, _p, _u64, _p, _p]),
+    "vith_backward": (_int, [_p, _p, _u64, _p]),
+    "vith_predict": (_int, [_p, _p, _u64, _p]),
+    "vith_trainer_create": (_p, [_p, _f, _f, _f, _f, _p, _u64]),
+    "vith_trainer_destroy": (None, [_p]),
+    "vith_train_step": (_int, [_p, _p, _p, _u64, _f, _pf, _pf]),
+    "vith_step_forward": (_int, [_p, _p, _p, _u64, _f]),
+    "vith_num_stages": (_u64, [_p]),
+    "vith_step_backward_stage": (_int, [_p, _u64]),
+    "vith_stage_grad_range": (_int, [_p, _u64, _pu, _pu]),
+    "vith_step_update": (_int, [_p, _f, _f]),
+    "vith_step_result": (_int, [_p, _pf, _pf]),
+    "vith_eval_batch": (_int, [_p, _p, _p, _u64, _pf, _pf]),
+    "vith_cosine_warmup_lr": (_f, [_i64, _i64, _i64, _f]),
+    "vith_epoch_order": (_int, [_u64, _i32, _p]),
+    "vith_layer_create": (_p, [_int, _u64, _u64, _u64, _u64]),
+    "vith_layer_destroy": (None, [_p]),
+    "vith_layer_param_count": (_u64, [_p]),
+    "vith_layer_set_params": (_int, [_p, _p]),
+    "vith_layer_get_grads": (_int, [_p, _p]),
+    "vith_layer_forward": (_int, [_p, _p, _pu, _u64, _int, _p, _u64]),
+    "vith_layer_backward": (_int, [_p, _p, _pu, _u64, _p, _u64]),
+}
+
+_dll = None
+
+
+def dll():
+    global _dll
+    if _dll is None:
+        if not os.path.exists(LIB_PATH):
+            raise HostError(f"{LIB_PATH} is missing: build it with `make -C visiontransformer_amd` "
+                            "(or __graft_entry__.build()); there is no CPU fallback")
+        vitk.dll()  # libvitk.so first (libvit_host.so links against it)
+        d = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(d, name)
+            fn.restype, fn.argtypes = res, args
+        _dll = d
+    return _dll
+
+
+def _check(rc):
+    if rc != 0:
+        raise HostError(dll().vith_last_error().decode(errors="replace"))
+
+
+def _np(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data
+
+
+def init(device=0):
+    _check(dll().vith_init(device))
+
+
+def use_torch_stream():
+    """Enqueue all host-layer work on torch's current CUDA stream."""
+    import torch
+    _check(dll().vith_set_stream(torch.cuda.current_stream().cuda_stream))
+
+
+def seed(s):
+    _check(dll().vith_seed(s))
+
+
+def synchronize():
+    _check(dll().vith_synchronize())
+
+
+def cosine_warmup_lr(step, warmup, total, lr_max):
+    return dll().vith_cosine_warmup_lr(step, warmup, total, lr_max)
+
+
+def epoch_order(n, epoch):
+    out = np.zeros(n, dtype=np.uint64)
+    _check(dll().vith_epoch_order(n, epoch, out.ctypes.data))
+    return out
+
+
+def save_config(cfg, path):
+    _check(dll().vith_save_config(C.byref(cfg), os.fsencode(path)))
+
+
+def load_config(path):
+    cfg = Config()
+    _check(dll().vith_load_config(os.fsencode(path), C.byref(cfg)))
+    return cfg
+
+
+class Model:
+    """VisionTransformer handle."""
+
+    def __init__(self, cfg, patch_mode=vitk.PATCH_REFERENCE, dk_mode=vitk.DK_REFERENCE):
+        self.cfg = cfg
+        self.h = dll().vith_model_create(C.byref(cfg), patch_mode, dk_mode)
+        if not self.h:
+            raise HostError(dll().vith_last_error().decode(errors="replace"))
+        self.n = dll().vith_param_count(self.h)
+
+    def close(self):
+        if self.h:
+            dll().vith_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def param_shapes(self):
+        out = []
+        dims = (C.c_uint64 * 4)()
+        for i in range(dll().vith_param_tensors(self.h)):
+            r = dll().vith_param_shape(self.h, i, dims)
+            out.append(tuple(int(dims[k]) for k in range(r)))
+        return out
+
+    def set_params(self, flat):
+        a, p = _np(flat)
+        assert a.size == self.n, (a.size, self.n)
+        _check(dll().vith_set_params(self.h, p))
+
+    def get_params(self):
+        out = np.zeros(self.n, dtype=np.float32)
+        _check(dll().vith_get_params(self.h, out.ctypes.data))
+        return out
+
+    def get_grads(self):
+        out = np.zeros(self.n, dtype=np.float32)
+        _check(dll().vith_get_grads(self.h, out.ctypes.data))
+        return out
+
+    def params_device(self):
+        return dll().vith_params_device(self.h)
+
+    def grads_device(self):
+        return dll().vith_grads_device(self.h)
+
+    def save_weights(self, path):
+        _check(dll().vith_save_weights(self.h, os.fsencode(path)))
+
+    def load_weights(self, path):
+        _check(dll().vith_load_weights(self.h, os.fsencode(path)))
+
+    def forward(self, x, training=False, out=None):
+        import torch
+        B = x.shape[0]
+        if out is None:
+            out = torch.empty(B, self.cfg.num_classes, dtype=torch.float32, device=x.device)
+        _check(dll().vith_forward(self.h, x.data_ptr(), B, int(training), out.data_ptr()))
+        return out
+
+    def forward_trace(self, x):
+        import torch
+        B, c = x.shape[0], self.cfg
+        acts = torch.empty(c.num_layers + 2, B, c.tokens, c.embedding_dim, dtype=torch.float32, device=x.device)
+        logits = torch.empty(B, c.num_classes, dtype=torch.float32, device=x.device)
+        _check(dll().vith_forward_trace(self.h, x.data_ptr(), B, acts.data_ptr(), logits.data_ptr()))
+        return acts, logits
+
+    def backward(self, dlogits, trace=False):
+        import torch
+        B, c = dlogits.shape[0], self.cfg
+        dacts = None
+        if trace:
+            dacts = torch.empty(c.num_layers + 1, B, c.tokens, c.embedding_dim, dtype=torch.float32,
+                                device=dlogits.device)
+        _check(dll().vith_backward(self.h, dlogits.data_ptr(), B, dacts.data_ptr() if trace else None))
+        return dacts
+
+    def predict(self, x):
+        import torch
+        out = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+        _check(dll().vith_predict(self.h, x.data_ptr(), x.shape[0], out.data_ptr()))
+        return out
+
+
+class Trainer:
+    """CrossEntropy + Adam(L2) around one Model: the per-batch body of the reference's Trainer."""
+
+    def __init__(self, model, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4, class_weights=None):
+        self.model = model
+        w, n = None, 0
+        if class_weights is not None:
+            self._w, w = _np(class_weights)
+            n = self._w.size
+        self.h = dll().vith_trainer_create(model.h, beta1, beta2, eps, weight_decay, w, n)
+        if not self.h:
+            raise HostError(dll().vith_last_error().decode(errors="replace"))
+        self.num_stages = dll().vith_num_stages(self.h)
+
+    def close(self):
+        if self.h:
+            dll().vith_trainer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def train_step(self, x, y, lr, want_result=True):
+        loss, ok = C.c_float(), C.c_float()
+        _check(dll().vith_train_step(self.h, x.data_ptr(), y.data_ptr(), x.shape[0], lr,
+                                     C.byref(loss) if want_result else None, C.byref(ok) if want_result else None))
+        return (loss.value, ok.value) if want_result else None
+
+    def step_forward(self, x, y, grad_batch=0.0):
+        _check(dll().vith_step_forward(self.h, x.data_ptr(), y.data_ptr(), x.shape[0], grad_batch))
+
+    def backward_stage(self, s):
+        _check(dll().vith_step_backward_stage(self.h, s))
+
+    def stage_grad_range(self, s):
+        o, c = C.c_uint64(), C.c_uint64()
+        _check(dll().vith_stage_grad_range(self.h, s, C.byref(o), C.byref(c)))
+        return o.value, c.value
+
+    def update(self, lr, grad_scale=1.0):
+        _check(dll().vith_step_update(self.h, lr, grad_scale))
+
+    def result(self):
+        loss, ok = C.c_float(), C.c_float()
+        _check(dll().vith_step_result(self.h, C.byref(loss), C.byref(ok)))
+        return loss.value, ok.value
+
+    def eval_batch(self, x, y):
+        loss, ok = C.c_float(), C.c_float()
+        _check(dll().vith_eval_batch(self.h, x.data_ptr(), y.data_ptr(), x.shape[0], C.byref(loss), C.byref(ok)))
+        return loss.value, ok.value
+
+
+LAYER_KINDS = {"dense": 0, "layernorm": 1, "gelu": 2, "mha": 3, "ffn": 4, "block": 5, "embeddings": 6}
+
+
+class Layer:
+    """One reference Layer subclass (host-buffer in/out; for op-level parity tests)."""
+
+    def __init__(self, kind, a=0, b=0, c=0, d=0):
+        self.h = dll().vith_layer_create(LAYER_KINDS[kind], a, b, c, d)
+        if not self.h:
+            raise HostError(dll().vith_last_error().decode(errors="replace"))
+        self.n = dll().vith_layer_param_count(self.h)
+
+    def close(self):
+        if self.h:
+            dll().vith_layer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_params(self, flat):
+        a, p = _np(flat)
+        assert a.size == self.n, (a.size, self.n)
+        _check(dll().vith_layer_set_params(self.h, p))
+
+    def get_grads(self):
+        out = np.zeros(self.n, dtype=np.float32)
+        _check(dll().vith_layer_get_grads(self.h, out.ctypes.data))
+        return out
+
+    def forward(self, x, out_shape, training=True):
+        a, p = _np(x)
+        shp = (C.c_uint64 * a.ndim)(*a.shape)
+        out = np.zeros(out_shape, dtype=np.float32)
+        _check(dll().vith_layer_forward(self.h, p, shp, a.ndim, int(training), out.ctypes.data, out.size))
+        return out
+
+    def backward(self, dy, dx_shape=None):
+        a, p = _np(dy)
+        shp = (C.c_uint64 * a.ndim)(*a.shape)
+        if dx_shape is None:
+            _check(dll().vith_layer_backward(self.h, p, shp, a.ndim, None, 0))
+            return None
+        out = np.zeros(dx_shape, dtype=np.float32)
+        _check(dll().vith_layer_backward(self.h, p, shp, a.ndim, out.ctypes.data, out.size))
+        return out

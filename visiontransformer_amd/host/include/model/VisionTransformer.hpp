@@ -1,0 +1,80 @@
+// VisionTransformer + ViTConfig (reference: include/model/VisionTransformer.hpp,
+// src/model/VisionTransformer.cpp): embeddings -> L encoder blocks -> final LayerNorm over all
+// tokens -> CLS row -> classification head.  Parameter order (getParameters): embeddings (4),
+// blocks (16 each), final norm (2), head (2).  All parameters and all gradients live in two flat
+// device arenas owned by the model.
+#ifndef VISIONTRANSFORMER_HPP
+#define VISIONTRANSFORMER_HPP
+
+#include <memory>
+#include <vector>
+
+#include "layers/Dense.hpp"
+#include "layers/Embeddings.hpp"
+#include "layers/Layer.hpp"
+#include "layers/LayerNorm.hpp"
+#include "model/TransformerEncoderBlock.hpp"
+
+struct ViTConfig {
+  size_t image_size = 28;
+  size_t patch_size = 7;
+  size_t in_channels = 1;
+  size_t num_classes = 10;
+  size_t embedding_dim = 128;
+  size_t num_heads = 8;
+  size_t num_layers = 4;
+  size_t mlp_hidden_dim = 512;
+  float dropout_rate = 0.1;
+};
+
+class VisionTransformer : public Layer {
+public:
+  explicit VisionTransformer(const ViTConfig &config);
+
+  Tensor forward(const Tensor &input, bool isTraining) override;
+  Tensor backward(const Tensor &outputGradient) override;
+  std::vector<Tensor *> getParameters() override;
+  std::vector<Tensor *> getGradients() override;
+  std::string getName() const override { return "VisionTransformer"; }
+
+  const ViTConfig &getConfig() const { return config; }
+  static size_t parameterCount(const ViTConfig &config);
+
+  // ---- extensions used by the data-parallel driver and the parity tests -----------------------
+  // Flat arenas (device layout; q/k/v weights packed as one {D,3D} block per layer).
+  vit::ParamArena &arena() { return *params; }
+  // Backward in stages, in the order gradients become final:
+  //   stage 0: head + final norm; stage 1..L: block L-1..0; stage L+1: embeddings.
+  size_t numBackwardStages() const { return encoder_blocks.size() + 2; }
+  void backwardBegin(const Tensor &outputGradient);
+  void backwardStage(size_t stage);
+  // [offset, offset+count) of the gradient arena finalised by `stage`
+  void stageGradientRange(size_t stage, size_t *offset, size_t *count) const;
+  // token stream after embeddings / each block / final norm of the last forward ((L+2) tensors),
+  // kept only when tracing is on
+  void setTrace(bool on) { trace = on; }
+  const std::vector<Tensor> &tracedActivations() const { return traceActs; }
+  const std::vector<Tensor> &tracedGradients() const { return traceGrads; }
+  std::vector<TransformerEncoderBlock> &blocks() { return encoder_blocks; }
+  Embeddings &getEmbeddings() { return embeddings; }
+
+private:
+  static std::vector<TransformerEncoderBlock> makeBlocks(const ViTConfig &c, vit::ParamArena &arena,
+                                                         std::vector<size_t> &offsets);
+
+private:
+  ViTConfig config;
+  std::unique_ptr<vit::ParamArena> params;
+  std::vector<size_t> stageOffsets;  // arena offsets: [0, end of embeddings, end of block 0, ..., end]
+  Embeddings embeddings;
+  std::vector<TransformerEncoderBlock> encoder_blocks;
+  LayerNorm final_norm;
+  Dense mlp_head;
+  size_t num_tokens;
+  Tensor final_norm_output;
+  Tensor stageGrad;
+  bool trace = false;
+  std::vector<Tensor> traceActs, traceGrads;
+};
+
+#endif  // VISIONTRANSFORMER_HPP

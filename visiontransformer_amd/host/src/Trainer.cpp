@@ -1,0 +1,116 @@
+// Trainer (reference: src/model/Trainer.cpp): epoch loop, per-epoch deterministic shuffle,
+// cosine/warm-up schedule, Adam(L2), evaluation on slices, CSV log and console summary.
+#include "model/Trainer.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <numeric>
+#include <random>
+#include <sstream>
+
+#include "optimizers/Scheduler.hpp"
+
+Trainer::Trainer(VisionTransformer &model, const TrainerConfig &train_config, const std::vector<float> &class_weights)
+    : model(model), optimizer(train_config.learning_rate, 0.9f, 0.999f, 1e-8f, train_config.weight_decay), loss_fn(),
+      config(train_config), logger("vit_results.csv") {
+  loss_fn.setClassWeights(class_weights);
+}
+
+// forward(train) -> loss/accuracy -> loss gradient -> model backward -> LR -> Adam
+// (src/model/Trainer.cpp:201-227).  Top-1 hits come out of the fused loss kernel.
+float Trainer::trainStep(const Tensor &X_batch, const Tensor &y_batch, float lr_now, float *accuracy) {
+  Tensor logits = model.forward(X_batch, true);
+  const float batch_loss = loss_fn.calculate(logits, y_batch);
+  if (accuracy) *accuracy = loss_fn.lastCorrect() / static_cast<float>(X_batch.getShape()[0]);
+  Tensor grad = loss_fn.backward(logits, y_batch);
+  model.backward(grad);
+  auto params = model.getParameters();
+  auto grads = model.getGradients();
+  optimizer.setLearningRate(lr_now);
+  optimizer.update(params, grads);
+  return batch_loss;
+}
+
+void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair<Tensor, Tensor> &test_data) {
+  const Tensor &X_train = train_data.first, &y_train = train_data.second;
+  const Tensor &X_test = test_data.first, &y_test = test_data.second;
+  const size_t batches_per_epoch = (X_train.getShape()[0] + config.batch_size - 1) / config.batch_size;
+  total_steps = (long long)batches_per_epoch * config.epochs;
+  for (int epoch = 0; epoch < config.epochs; ++epoch) {
+    const auto start = std::chrono::high_resolution_clock::now();
+    auto [train_loss, train_acc] = train_epoch(X_train, y_train, epoch);
+    if (!quiet) std::cout << "\r" << std::string(80, ' ') << "\r";
+    auto [test_loss, test_acc] = evaluate(X_test, y_test);
+    const auto ms_total =
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
+    logger.log_epoch(epoch, config.epochs, train_loss, train_acc, test_loss, test_acc);
+    std::ostringstream t;
+    t << std::setfill('0') << "[" << std::setw(2) << ms_total / 3600000 << ":" << std::setw(2)
+      << (ms_total % 3600000) / 60000 << ":" << std::setw(2) << (ms_total % 60000) / 1000 << "." << std::setw(3)
+      << ms_total % 1000 << "]";
+    std::cout << "\033[1m--- Epoch " << (epoch + 1) << "/" << config.epochs << "\033[0m | \033[1;34mTrain Loss: "
+              << std::fixed << std::setprecision(4) << train_loss << " | Train Acc: " << train_acc
+              << "\033[0m | \033[1;32mTest Loss: " << test_loss << " | Test Acc: " << test_acc << "\033[0m \033[1;35m"
+              << t.str() << "\033[0m" << std::endl;
+  }
+}
+
+std::pair<float, float> Trainer::train_epoch(const Tensor &X_train, const Tensor &y_train, int epoch) {
+  const auto &shape = X_train.getShape();
+  const size_t n = shape[0], sample = shape[1] * shape[2] * shape[3], K = y_train.getShape()[1];
+  const size_t num_batches = (n + config.batch_size - 1) / config.batch_size;
+  float total_loss = 0.0f, total_accuracy = 0.0f;
+  // sample order of the epoch: iota shuffled by mt19937(epoch) (src/model/Trainer.cpp:151-154)
+  std::vector<size_t> indices(n);
+  std::iota(indices.begin(), indices.end(), 0);
+  std::mt19937 rng(static_cast<uint32_t>(epoch));
+  std::shuffle(indices.begin(), indices.end(), rng);
+  Tensor Xs = X_train.dense(), ys = y_train.dense();
+  const float *xsrc = Xs.data(), *ysrc = ys.data();
+  std::vector<float> xb, yb;
+  for (size_t i = 0; i < num_batches; ++i) {
+    const size_t first = i * config.batch_size;
+    const size_t count = std::min(config.batch_size, n - first);
+    if (count == 0) continue;
+    xb.resize(count * sample);
+    yb.resize(count * K);
+    for (size_t j = 0; j < count; ++j) {
+      const size_t src = indices[first + j];
+      std::memcpy(xb.data() + j * sample, xsrc + src * sample, sample * sizeof(float));
+      std::memcpy(yb.data() + j * K, ysrc + src * K, K * sizeof(float));
+    }
+    Tensor X_batch({count, shape[1], shape[2], shape[3]}, xb), y_batch({count, K}, yb);
+    const long long warmup_steps = (long long)(config.warmup_frac * total_steps);
+    const float lr_now = cosine_warmup_lr(global_step, warmup_steps, total_steps, config.lr_init);
+    float acc = 0.0f;
+    const float batch_loss = trainStep(X_batch, y_batch, lr_now, &acc);
+    total_loss += batch_loss;
+    total_accuracy += acc;
+    global_step++;
+    if (!quiet)
+      std::cout << "\rEntrenando... Batch " << (i + 1) << "/" << num_batches << " [loss: " << std::fixed
+                << std::setprecision(8) << batch_loss << "]"
+                << " | LR: " << std::fixed << std::setprecision(8) << optimizer.getLearningRate() << std::flush;
+  }
+  return {total_loss / num_batches, total_accuracy / num_batches};
+}
+
+std::pair<float, float> Trainer::evaluate(const Tensor &X_test, const Tensor &y_test) {
+  const size_t n = X_test.getShape()[0];
+  const size_t num_batches = (n + config.batch_size - 1) / config.batch_size;
+  float total_loss = 0.0f, total_accuracy = 0.0f;
+  for (size_t i = 0; i < num_batches; ++i) {
+    const size_t start = i * config.batch_size;
+    const size_t count = std::min(config.batch_size, n - start);
+    if (count == 0) continue;
+    Tensor X_batch = X_test.slice(0, start, count), y_batch = y_test.slice(0, start, count);
+    Tensor logits = model.forward(X_batch, false);
+    total_loss += loss_fn.calculate(logits, y_batch);
+    total_accuracy += loss_fn.lastCorrect() / static_cast<float>(count);
+  }
+  if (num_batches == 0) return {0.0f, 0.0f};
+  return {total_loss / num_batches, total_accuracy / num_batches};
+}

@@ -1,0 +1,353 @@
+// C-ABI over the host layer (include/vit_host.h): opaque handles around the C++ classes, every
+// exception turned into a status code + thread-local message.
+#include "vit_host.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <string>
+
+#include "core/Device.hpp"
+#include "core/Ops.hpp"
+#include "model/Trainer.hpp"
+#include "optimizers/Scheduler.hpp"
+#include "utils/ModelUtils.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+template <typename F>
+int guard(F &&f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  } catch (...) {
+    g_err = "unknown exception";
+    return 1;
+  }
+}
+
+ViTConfig to_cfg(const vith_config *c) {
+  ViTConfig k;
+  k.image_size = c->image_size; k.patch_size = c->patch_size; k.in_channels = c->in_channels;
+  k.num_classes = c->num_classes; k.embedding_dim = c->embedding_dim; k.num_heads = c->num_heads;
+  k.num_layers = c->num_layers; k.mlp_hidden_dim = c->mlp_hidden_dim; k.dropout_rate = c->dropout_rate;
+  return k;
+}
+
+struct Model {
+  VisionTransformer vit;
+  explicit Model(const ViTConfig &c) : vit(c) {}
+  Tensor input(const float *x_dev, uint64_t B) {
+    const ViTConfig &c = vit.getConfig();
+    return Tensor::wrapDevice(const_cast<float *>(x_dev), {(size_t)B, c.in_channels, c.image_size, c.image_size});
+  }
+  size_t tokens() const {
+    const ViTConfig &c = vit.getConfig();
+    return 1 + (c.image_size / c.patch_size) * (c.image_size / c.patch_size);
+  }
+};
+
+struct TrainerState {
+  Model *model;
+  CrossEntropy loss;
+  Adam adam;
+  Tensor logits, labels;
+  TrainerState(Model *m, float b1, float b2, float eps, float wd) : model(m), adam(0.0f, b1, b2, eps, wd) {}
+};
+
+struct LayerBox {
+  std::unique_ptr<Layer> layer;
+};
+
+Model *M(vith_model m) { return static_cast<Model *>(m); }
+TrainerState *T(vith_trainer t) { return static_cast<TrainerState *>(t); }
+LayerBox *L(vith_layer l) { return static_cast<LayerBox *>(l); }
+
+void copy_out(const Tensor &t, float *dst_dev) {
+  Tensor d = t.dense();
+  vit::copy_on_device(dst_dev, d.deviceData(), d.getSize());
+}
+
+std::vector<size_t> shape_of(const uint64_t *s, uint64_t rank) {
+  std::vector<size_t> v(rank);
+  for (uint64_t i = 0; i < rank; ++i) v[i] = (size_t)s[i];
+  return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vith_last_error(void) { return g_err.c_str(); }
+int vith_init(int device) { return guard([&] { vit::init(device); }); }
+int vith_set_stream(void *s) { return guard([&] { vit::set_stream(s); }); }
+int vith_synchronize(void) { return guard([&] { vit::synchronize(); }); }
+int vith_seed(uint64_t seed) { return guard([&] { vit::seed(seed); }); }
+uint64_t vith_device_bytes_in_use(void) { return vit::device_bytes_in_use(); }
+
+vith_model vith_model_create(const vith_config *cfg, int patch_mode, int dk_mode) {
+  Model *m = nullptr;
+  const int rc = guard([&] {
+    if (!cfg) throw std::invalid_argument("vith_model_create: null config");
+    PatchEmbedding::setDefaultPatchMode(patch_mode);
+    MultiHeadAttention::setDefaultKeyGradMode(dk_mode);
+    m = new Model(to_cfg(cfg));
+    PatchEmbedding::setDefaultPatchMode(VITK_PATCH_REFERENCE);
+    MultiHeadAttention::setDefaultKeyGradMode(VITK_DK_REFERENCE);
+  });
+  return rc ? nullptr : m;
+}
+void vith_model_destroy(vith_model m) { delete M(m); }
+
+uint64_t vith_param_count(vith_model m) { return VisionTransformer::parameterCount(M(m)->vit.getConfig()); }
+uint64_t vith_param_tensors(vith_model m) { return M(m)->vit.getParameters().size(); }
+uint64_t vith_param_shape(vith_model m, uint64_t idx, uint64_t *dims) {
+  auto p = M(m)->vit.getParameters();
+  if (idx >= p.size()) return 0;
+  const auto &s = p[idx]->getShape();
+  for (size_t i = 0; i < s.size() && i < 4; ++i) dims[i] = s[i];
+  return s.size();
+}
+int vith_get_params(vith_model m, float *flat) {
+  return guard([&] {
+    auto v = ModelUtils::flatten(M(m)->vit.getParameters());
+    std::memcpy(flat, v.data(), v.size() * sizeof(float));
+  });
+}
+int vith_set_params(vith_model m, const float *flat) {
+  return guard([&] { ModelUtils::unflatten(M(m)->vit.getParameters(), flat, vith_param_count(m)); });
+}
+int vith_get_grads(vith_model m, float *flat) {
+  return guard([&] {
+    auto v = ModelUtils::flatten(M(m)->vit.getGradients());
+    std::memcpy(flat, v.data(), v.size() * sizeof(float));
+  });
+}
+float *vith_params_device(vith_model m) { return M(m)->vit.arena().params()->dev_write(); }
+float *vith_grads_device(vith_model m) { return M(m)->vit.arena().grads()->dev_write(); }
+
+int vith_save_weights(vith_model m, const char *path) {
+  return guard([&] { ModelUtils::set_verbose(false); ModelUtils::save_weights(M(m)->vit, path); });
+}
+int vith_load_weights(vith_model m, const char *path) {
+  return guard([&] { ModelUtils::set_verbose(false); ModelUtils::load_weights(M(m)->vit, path); });
+}
+int vith_save_config(const vith_config *cfg, const char *path) {
+  return guard([&] { ModelUtils::set_verbose(false); ModelUtils::save_config(to_cfg(cfg), path); });
+}
+int vith_load_config(const char *path, vith_config *cfg) {
+  return guard([&] {
+    ModelUtils::set_verbose(false);
+    ViTConfig k = ModelUtils::load_config(path);
+    cfg->image_size = k.image_size; cfg->patch_size = k.patch_size; cfg->in_channels = k.in_channels;
+    cfg->num_classes = k.num_classes; cfg->embedding_dim = k.embedding_dim; cfg->num_heads = k.num_heads;
+    cfg->num_layers = k.num_layers; cfg->mlp_hidden_dim = k.mlp_hidden_dim; cfg->dropout_rate = k.dropout_rate;
+  });
+}
+
+int vith_forward(vith_model m, const float *x_dev, uint64_t B, int training, float *logits_dev) {
+  return guard([&] {
+    Tensor out = M(m)->vit.forward(M(m)->input(x_dev, B), training != 0);
+    copy_out(out, logits_dev);
+  });
+}
+
+int vith_forward_trace(vith_model m, const float *x_dev, uint64_t B, float *acts_dev, float *logits_dev) {
+  return guard([&] {
+    VisionTransformer &v = M(m)->vit;
+    v.setTrace(true);
+    Tensor out = v.forward(M(m)->input(x_dev, B), true);
+    v.setTrace(false);
+    size_t off = 0;
+    for (const Tensor &t : v.tracedActivations()) {
+      copy_out(t, acts_dev + off);
+      off += t.getSize();
+    }
+    copy_out(out, logits_dev);
+  });
+}
+
+int vith_backward(vith_model m, const float *dlogits_dev, uint64_t B, float *dacts_dev) {
+  return guard([&] {
+    VisionTransformer &v = M(m)->vit;
+    Tensor g = Tensor::wrapDevice(const_cast<float *>(dlogits_dev), {(size_t)B, v.getConfig().num_classes});
+    v.setTrace(dacts_dev != nullptr);
+    v.backward(g);
+    v.setTrace(false);
+    if (dacts_dev) {
+      size_t off = 0;
+      for (const Tensor &t : v.tracedGradients()) {
+        copy_out(t, dacts_dev + off);
+        off += t.getSize();
+      }
+    }
+  });
+}
+
+int vith_predict(vith_model m, const float *x_dev, uint64_t B, int32_t *pred_dev) {
+  return guard([&] {
+    Tensor logits = M(m)->vit.forward(M(m)->input(x_dev, B), false);
+    Tensor probs = softmax(logits);
+    vit::check(vitk_argmax_rows(probs.deviceData(), (int32_t)B, (int32_t)M(m)->vit.getConfig().num_classes, pred_dev,
+                                vit::stream()),
+               "vitk_argmax_rows");
+  });
+}
+
+vith_trainer vith_trainer_create(vith_model m, float beta1, float beta2, float eps, float weight_decay,
+                                 const float *class_weights, uint64_t n_weights) {
+  TrainerState *t = nullptr;
+  const int rc = guard([&] {
+    t = new TrainerState(M(m), beta1, beta2, eps, weight_decay);
+    if (class_weights && n_weights) t->loss.setClassWeights(std::vector<float>(class_weights, class_weights + n_weights));
+  });
+  return rc ? nullptr : t;
+}
+void vith_trainer_destroy(vith_trainer t) { delete T(t); }
+
+int vith_step_forward(vith_trainer t, const float *x_dev, const float *y_dev, uint64_t B, float grad_batch) {
+  return guard([&] {
+    TrainerState *s = T(t);
+    VisionTransformer &v = s->model->vit;
+    s->logits = v.forward(s->model->input(x_dev, B), true);
+    s->labels = Tensor::wrapDevice(const_cast<float *>(y_dev), {(size_t)B, v.getConfig().num_classes});
+    s->loss.setGradientBatch(grad_batch);
+    s->loss.enqueue(s->logits, s->labels);
+    v.backwardBegin(s->loss.backward(s->logits, s->labels));
+  });
+}
+uint64_t vith_num_stages(vith_trainer t) { return T(t)->model->vit.numBackwardStages(); }
+int vith_step_backward_stage(vith_trainer t, uint64_t stage) {
+  return guard([&] { T(t)->model->vit.backwardStage((size_t)stage); });
+}
+int vith_stage_grad_range(vith_trainer t, uint64_t stage, uint64_t *offset, uint64_t *count) {
+  return guard([&] {
+    size_t o, c;
+    T(t)->model->vit.stageGradientRange((size_t)stage, &o, &c);
+    *offset = o;
+    *count = c;
+  });
+}
+int vith_step_update(vith_trainer t, float lr, float grad_scale) {
+  return guard([&] {
+    TrainerState *s = T(t);
+    auto p = s->model->vit.getParameters();
+    auto g = s->model->vit.getGradients();
+    s->adam.setLearningRate(lr);
+    s->adam.setGradientScale(grad_scale);
+    s->adam.update(p, g);
+  });
+}
+int vith_step_result(vith_trainer t, float *loss, float *correct) {
+  return guard([&] {
+    const float *r = T(t)->loss.resultBuffer().data();
+    if (loss) *loss = r[0];
+    if (correct) *correct = r[1];
+  });
+}
+int vith_train_step(vith_trainer t, const float *x_dev, const float *y_dev, uint64_t B, float lr, float *loss,
+                    float *correct) {
+  if (vith_step_forward(t, x_dev, y_dev, B, 0.0f)) return 1;
+  const uint64_t n = vith_num_stages(t);
+  for (uint64_t s = 0; s < n; ++s)
+    if (vith_step_backward_stage(t, s)) return 1;
+  if (vith_step_update(t, lr, 1.0f)) return 1;
+  if (loss || correct) return vith_step_result(t, loss, correct);
+  return 0;
+}
+int vith_eval_batch(vith_trainer t, const float *x_dev, const float *y_dev, uint64_t B, float *loss, float *correct) {
+  return guard([&] {
+    TrainerState *s = T(t);
+    VisionTransformer &v = s->model->vit;
+    Tensor logits = v.forward(s->model->input(x_dev, B), false);
+    Tensor y = Tensor::wrapDevice(const_cast<float *>(y_dev), {(size_t)B, v.getConfig().num_classes});
+    s->loss.setGradientBatch(0.0f);
+    const float l = s->loss.calculate(logits, y);
+    if (loss) *loss = l;
+    if (correct) *correct = s->loss.lastCorrect();
+  });
+}
+
+float vith_cosine_warmup_lr(int64_t step, int64_t warmup, int64_t total, float lr_max) {
+  return cosine_warmup_lr(step, warmup, total, lr_max);
+}
+
+int vith_epoch_order(uint64_t n, int32_t epoch, uint64_t *out) {
+  return guard([&] {
+    std::vector<size_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::mt19937 rng(static_cast<uint32_t>(epoch));
+    std::shuffle(idx.begin(), idx.end(), rng);
+    for (uint64_t i = 0; i < n; ++i) out[i] = idx[i];
+  });
+}
+
+vith_layer vith_layer_create(int kind, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+  LayerBox *box = nullptr;
+  const int rc = guard([&] {
+    std::unique_ptr<Layer> l;
+    switch (kind) {
+      case 0: l = std::make_unique<Dense>(a, b); break;
+      case 1: l = std::make_unique<LayerNorm>(a); break;
+      case 2: l = std::make_unique<GELU>(); break;
+      case 3: l = std::make_unique<MultiHeadAttention>(a, b); break;
+      case 4: l = std::make_unique<FeedForward>(a, b, 0.0f); break;
+      case 5: l = std::make_unique<TransformerEncoderBlock>(a, b, c, 0.0f); break;
+      case 6: l = std::make_unique<Embeddings>(a, a, b, c, d); break;
+      default: throw std::invalid_argument("vith_layer_create: unknown kind");
+    }
+    box = new LayerBox{std::move(l)};
+  });
+  return rc ? nullptr : box;
+}
+void vith_layer_destroy(vith_layer l) { delete L(l); }
+uint64_t vith_layer_param_count(vith_layer l) {
+  uint64_t n = 0;
+  for (Tensor *t : L(l)->layer->getParameters()) n += t->getSize();
+  return n;
+}
+int vith_layer_set_params(vith_layer l, const float *flat) {
+  return guard([&] { ModelUtils::unflatten(L(l)->layer->getParameters(), flat, vith_layer_param_count(l)); });
+}
+int vith_layer_get_grads(vith_layer l, float *flat) {
+  return guard([&] {
+    auto v = ModelUtils::flatten(L(l)->layer->getGradients());
+    std::memcpy(flat, v.data(), v.size() * sizeof(float));
+  });
+}
+int vith_layer_forward(vith_layer l, const float *x, const uint64_t *x_shape, uint64_t x_rank, int training, float *y,
+                       uint64_t y_count) {
+  return guard([&] {
+    auto shape = shape_of(x_shape, x_rank);
+    size_t n = 1;
+    for (size_t s : shape) n *= s;
+    Tensor in(shape, std::vector<float>(x, x + n));
+    Tensor out = L(l)->layer->forward(in, training != 0);
+    if (out.getSize() != y_count) throw std::runtime_error("vith_layer_forward: output size mismatch");
+    Tensor d = out.dense();
+    std::memcpy(y, static_cast<const Tensor &>(d).data(), y_count * sizeof(float));
+  });
+}
+int vith_layer_backward(vith_layer l, const float *dy, const uint64_t *dy_shape, uint64_t dy_rank, float *dx,
+                        uint64_t dx_count) {
+  return guard([&] {
+    auto shape = shape_of(dy_shape, dy_rank);
+    size_t n = 1;
+    for (size_t s : shape) n *= s;
+    Tensor g(shape, std::vector<float>(dy, dy + n));
+    Tensor out = L(l)->layer->backward(g);
+    if (!dx) return;
+    if (!out.defined()) throw std::runtime_error("vith_layer_backward: this layer produces no input gradient");
+    if (out.getSize() != dx_count) throw std::runtime_error("vith_layer_backward: gradient size mismatch");
+    Tensor d = out.dense();
+    std::memcpy(dx, static_cast<const Tensor &>(d).data(), dx_count * sizeof(float));
+  });
+}
+
+}  // extern "C"

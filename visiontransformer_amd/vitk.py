@@ -56,7 +56,9 @@ SIGNATURES = {
     "vitk_add3_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p]),
     "vitk_scale_f32": (C.c_int, [_p, _f, _i64, _p, _p]),
     "vitk_fill_f32": (C.c_int, [_p, _f, _i64, _p]),
+    "vitk_add_rowvec_f32": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "vitk_copy2d_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
+    "vitk_copy4d_f32": (C.c_int, [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _p, _p]),
     "vitk_softmax_rows": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),
     "vitk_softmax_rows_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _f, _p, _p]),
     "vitk_dk_reference_scatter": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
