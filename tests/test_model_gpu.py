@@ -166,7 +166,8 @@ def test_model_activations_gradients_and_steps_match_reference(H, name):
     dacts = host_np(m.backward(dev(g["dlogits"]), trace=True))
     for i in range(L + 1):
         close(dacts[i], g["dacts"][i], GRAD_TOL, f"activation gradient {i}")
-    np.testing.assert_array_equal(m.get_grads(), grads)  # staged == monolithic, bitwise
+    # (this backward started from the reference's dlogits, the staged one from the fused CE kernel's)
+    close(m.get_grads(), grads, 1e-5, "monolithic vs staged backward")
     # optimisation steps (fresh model state: the golden run had not stepped yet either)
     for s in range(steps):
         lr = H.cosine_warmup_lr(s + 1, 2, steps + 2, 3e-4)
@@ -305,7 +306,9 @@ def test_im2col_mode_reads_true_patches_and_exact_dk_matches_autograd(H):
     off = 0
     for i, (p_, s) in enumerate(zip(ps, V.param_shapes(c))):
         k = int(np.prod(s))
-        close(grads[off:off + k], p_.grad.numpy().ravel(), GRAD_TOL, f"autograd grad tensor {i}")
+        # (the key-bias gradient is identically zero -- softmax rows of dS sum to 0 -- hence the floor)
+        e = V.max_relerr(grads[off:off + k], p_.grad.numpy().ravel(), floor=1e-5)
+        assert e <= GRAD_TOL, f"autograd grad tensor {i}: {e:.3e}"
         off += k
 
 
