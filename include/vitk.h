@@ -90,6 +90,15 @@ int vitk_gemm_f32(const vitk_gemm_args *args, vitk_stream_t stream);
 /* Bytes of workspace vitk_gemm_f32 needs for these arguments (0 when it will not split K). */
 size_t vitk_gemm_workspace_bytes(const vitk_gemm_args *args);
 
+/* Measurement aid for bench.py (not used by the training path): while enabled, every main
+ * contraction launch is bracketed by two HIP events on its stream.  variant = 4*(tile==64) +
+ * 2*trans_a + trans_b identifies the kernel instantiation (vitk_gemm_variant_name gives the name a
+ * profiler shows); vitk_gemm_profile_read returns the summed event time, the summed algorithmic
+ * FLOPs (2*M*N*K*batch) and the launch count of one variant, optionally clearing all records. */
+int vitk_gemm_profile_enable(int on);
+int vitk_gemm_profile_read(int variant, double *total_ms, double *total_flops, int64_t *launches, int reset);
+const char *vitk_gemm_variant_name(int variant);
+
 /* ---- column sum: out[j] = sum_i x[i][j]  (Tensor::sum(0), src/core/Tensor.cpp:385-430; the
  * bias gradient of Dense::backward, src/layers/Dense.cpp:95, and dpos/dcls of
  * Embeddings::backward, src/layers/Embeddings.cpp:43,50).  Two-stage, fixed order.

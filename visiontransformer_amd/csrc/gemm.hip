@@ -15,6 +15,8 @@
 // 2 the LDS traffic is only 2*NT operand reads against NT^2 MFMAs: the loop is MFMA-paced.
 #include "common.h"
 
+#include <vector>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -319,6 +321,31 @@ bool strides_vec_ok(const float *p, long long ld, long long so, long long si) {
   return vitk::aligned16(p) && ld % 4 == 0 && so % 4 == 0 && si % 4 == 0;
 }
 
+// ---- optional per-launch timing (measurement only) -------------------------------------------
+// When enabled, every main GEMM launch is bracketed by two HIP events on its own stream and
+// tagged with its kernel variant and algorithmic FLOPs; vitk_gemm_profile_read sums them up.
+struct ProfRec {
+  int variant;
+  double flops;
+  hipEvent_t e0, e1;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t prof_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int variant_of(int tile, bool ta, bool tb) { return (tile == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0); }
+
 }  // namespace
 
 extern "C" size_t vitk_gemm_workspace_bytes(const vitk_gemm_args *a) {
@@ -369,11 +396,20 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
 
   hipStream_t st = vitk::as_stream(stream);
   dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)(pl.batch * pl.split_k), 1);
-  if (a->K == 0) {
-    // empty contraction: acc = 0 everywhere; the kernel handles nslab == 0
+  ProfRec rec{};
+  if (g_prof_on) {
+    rec.variant = variant_of(pl.tile, a->trans_a != 0, a->trans_b != 0);
+    rec.flops = 2.0 * a->M * a->N * a->K * pl.batch;
+    rec.e0 = prof_event();
+    rec.e1 = prof_event();
+    (void)hipEventRecord(rec.e0, st);
   }
   if (pl.tile == 128) launch<128>(p, a->trans_a != 0, a->trans_b != 0, grid, st);
   else launch<64>(p, a->trans_a != 0, a->trans_b != 0, grid, st);
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.e1, st);
+    g_prof.push_back(rec);
+  }
   if (vitk::check_launch("vitk_gemm_f32")) return 1;
   if (pl.split_k > 1) {
     const long long total = (long long)pl.batch * a->M * a->N;
@@ -382,4 +418,46 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
     if (vitk::check_launch("vitk_gemm_f32/splitk_reduce")) return 1;
   }
   return 0;
+}
+
+extern "C" int vitk_gemm_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *total_flops, int64_t *launches,
+                                      int reset) {
+  VITK_REQUIRE(variant >= 0 && variant < 8, "vitk_gemm_profile_read: variant %d outside [0,8)", variant);
+  double ms = 0.0, fl = 0.0;
+  int64_t n = 0;
+  for (const ProfRec &r : g_prof) {
+    if (r.variant != variant) continue;
+    hipError_t e = hipEventSynchronize(r.e1);
+    VITK_REQUIRE(e == hipSuccess, "vitk_gemm_profile_read: %s", hipGetErrorString(e));
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.e0, r.e1);
+    VITK_REQUIRE(e == hipSuccess, "vitk_gemm_profile_read: %s", hipGetErrorString(e));
+    ms += t;
+    fl += r.flops;
+    ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  if (reset) {
+    for (const ProfRec &r : g_prof) {
+      g_event_pool.push_back(r.e0);
+      g_event_pool.push_back(r.e1);
+    }
+    g_prof.clear();
+  }
+  return 0;
+}
+
+extern "C" const char *vitk_gemm_variant_name(int variant) {
+  static const char *names[8] = {
+      "gemm_kernel<128, false, false>", "gemm_kernel<128, false, true>", "gemm_kernel<128, true, false>",
+      "gemm_kernel<128, true, true>",   "gemm_kernel<64, false, false>", "gemm_kernel<64, false, true>",
+      "gemm_kernel<64, true, false>",   "gemm_kernel<64, true, true>"};
+  return (variant >= 0 && variant < 8) ? names[variant] : "";
 }

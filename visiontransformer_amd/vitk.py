@@ -43,6 +43,10 @@ SIGNATURES = {
     "vitk_init": (C.c_int, [C.c_int]),
     "vitk_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
     "vitk_gemm_workspace_bytes": (_sz, [C.POINTER(GemmArgs)]),
+    "vitk_gemm_profile_enable": (C.c_int, [C.c_int]),
+    "vitk_gemm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int64), C.c_int]),
+    "vitk_gemm_variant_name": (C.c_char_p, [C.c_int]),
     "vitk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "vitk_colsum_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "vitk_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
@@ -149,3 +153,21 @@ def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=Non
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * 4
     check(dll().vitk_gemm_f32(C.byref(a), st if st is not None else stream()))
     return keep
+
+
+def gemm_profile(enable):
+    check(dll().vitk_gemm_profile_enable(int(enable)))
+
+
+def gemm_profile_read(reset=True):
+    """Per kernel variant: dict(name, ms, flops, launches) for variants that were launched."""
+    out = []
+    for v in range(8):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        check(dll().vitk_gemm_profile_read(v, C.byref(ms), C.byref(fl), C.byref(n), 0))
+        if n.value:
+            out.append(dict(name=dll().vitk_gemm_variant_name(v).decode(), ms=ms.value, flops=fl.value,
+                            launches=n.value))
+    if reset:
+        check(dll().vitk_gemm_profile_read(0, None, None, None, 1))
+    return out
