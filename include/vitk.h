@@ -91,8 +91,8 @@ int vitk_gemm_f32(const vitk_gemm_args *args, vitk_stream_t stream);
 size_t vitk_gemm_workspace_bytes(const vitk_gemm_args *args);
 
 /* Measurement aid for bench.py (not used by the training path): while enabled, every main
- * contraction launch is bracketed by two HIP events on its stream.  variant = 4*(tile==64) +
- * 2*trans_a + trans_b identifies the kernel instantiation (vitk_gemm_variant_name gives the name a
+ * contraction launch is bracketed by two HIP events on its stream.  variant = 8*full +
+ * 4*(tile==64) + 2*trans_a + trans_b (0..15) identifies the kernel instantiation (vitk_gemm_variant_name gives the name a
  * profiler shows); vitk_gemm_profile_read returns the summed event time, the summed algorithmic
  * FLOPs (2*M*N*K*batch) and the launch count of one variant, optionally clearing all records. */
 int vitk_gemm_profile_enable(int on);

@@ -20,9 +20,14 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native vector (not HIP's f32x4 struct): keeps the staging registers out of scratch memory
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 constexpr int THREADS = 256;
+// Workgroups resident per CU (= waves per SIMD) the kernels are compiled for; the split-K plan
+// sizes its grid to one full round of these.
+constexpr int kBlocksPerCU = 3;
 
 struct Params {
   int M, N, K;
@@ -54,17 +59,17 @@ struct KContig {
   static constexpr int NL = ROWS * BK / 4 / THREADS;
   static constexpr int LD = ROWS + 2;
   __device__ static void load(const float *__restrict__ base, long long ld, int row0, int rows, int k0, int kend,
-                              bool vec, float4 (&reg)[NL]) {
+                              bool vec, f32x4 (&reg)[NL]) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int q = threadIdx.x + THREADS * it;
       const int r = q / (BK / 4), kq = q % (BK / 4);
       const int row = row0 + r, k = k0 + kq * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < rows && k < kend) {
         const float *p = base + (long long)row * ld + k;
         if (vec && k + 3 < kend) {
-          v = *reinterpret_cast<const float4 *>(p);
+          v = *reinterpret_cast<const f32x4 *>(p);
         } else {
           v.x = p[0];
           if (k + 1 < kend) v.y = p[1];
@@ -75,7 +80,19 @@ struct KContig {
       reg[it] = v;
     }
   }
-  __device__ static void store(float *__restrict__ s, const float4 (&reg)[NL]) {
+  // FULL path: per-lane byte offsets inside the tile (constant over the K loop); the tile origin
+  // is a uniform pointer that advances by slab_bytes() per slab, so the loop needs no vector
+  // address arithmetic.
+  __device__ static void lane_offsets(long long ld, unsigned (&off)[NL]) {
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int q = threadIdx.x + THREADS * it;
+      off[it] = (unsigned)(((q / (BK / 4)) * ld + (q % (BK / 4)) * 4) * 4);
+    }
+  }
+  __device__ static long long origin(long long ld, int row0, int k0) { return (long long)row0 * ld + k0; }
+  __device__ static long long slab_bytes(long long) { return BK * 4; }
+  __device__ static void store(float *__restrict__ s, const f32x4 (&reg)[NL]) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int q = threadIdx.x + THREADS * it;
@@ -96,17 +113,17 @@ struct MnContig {
   static constexpr int NL = ROWS * BK / 4 / THREADS;
   static constexpr int LD = ROWS + 4;
   __device__ static void load(const float *__restrict__ base, long long ld, int row0, int rows, int k0, int kend,
-                              bool vec, float4 (&reg)[NL]) {
+                              bool vec, f32x4 (&reg)[NL]) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int q = threadIdx.x + THREADS * it;
       const int kk = q / (ROWS / 4), rq = q % (ROWS / 4);
       const int k = k0 + kk, row = row0 + rq * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (k < kend && row < rows) {
         const float *p = base + (long long)k * ld + row;
         if (vec && row + 3 < rows) {
-          v = *reinterpret_cast<const float4 *>(p);
+          v = *reinterpret_cast<const f32x4 *>(p);
         } else {
           v.x = p[0];
           if (row + 1 < rows) v.y = p[1];
@@ -117,12 +134,21 @@ struct MnContig {
       reg[it] = v;
     }
   }
-  __device__ static void store(float *__restrict__ s, const float4 (&reg)[NL]) {
+  __device__ static void lane_offsets(long long ld, unsigned (&off)[NL]) {
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int q = threadIdx.x + THREADS * it;
+      off[it] = (unsigned)(((q / (ROWS / 4)) * ld + (q % (ROWS / 4)) * 4) * 4);
+    }
+  }
+  __device__ static long long origin(long long ld, int row0, int k0) { return (long long)k0 * ld + row0; }
+  __device__ static long long slab_bytes(long long ld) { return BK * ld * 4; }
+  __device__ static void store(float *__restrict__ s, const f32x4 (&reg)[NL]) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int q = threadIdx.x + THREADS * it;
       const int kk = q / (ROWS / 4), rq = q % (ROWS / 4);
-      *reinterpret_cast<float4 *>(s + kk * LD + rq * 4) = reg[it];
+      *reinterpret_cast<f32x4 *>(s + kk * LD + rq * 4) = reg[it];
     }
   }
 };
@@ -134,8 +160,10 @@ struct Operand<true, ROWS> : KContig<ROWS> {};
 template <int ROWS>
 struct Operand<false, ROWS> : MnContig<ROWS> {};
 
-template <int TILE, bool TA, bool TB>
-__global__ __launch_bounds__(THREADS) void gemm_kernel(const Params p) {
+// FULL: every tile and every K slab is complete and both operands allow 16-byte loads, so the
+// loop carries no bounds checks at all (true for every large contraction of ViT-Ti/S/B).
+template <int TILE, bool TA, bool TB, bool FULL>
+__global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Params p) {
   using OpA = Operand<!TA, TILE>;  // A is k-contiguous when not transposed
   using OpB = Operand<TB, TILE>;   // B is k-contiguous when transposed
   constexpr int WT = TILE / 2;     // per-wave tile
@@ -172,11 +200,32 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[OpA::NL], rb[OpB::NL];
+  f32x4 ra[OpA::NL], rb[OpB::NL];
   const bool va = p.vec_a, vb = p.vec_b;
+  // FULL: uniform tile-origin pointers (scalar registers) + constant per-lane byte offsets
+  unsigned offa[OpA::NL], offb[OpB::NL];
+  const char *pa = reinterpret_cast<const char *>(A + OpA::origin(p.lda, m0, kbeg));
+  const char *pb = reinterpret_cast<const char *>(B + OpB::origin(p.ldb, n0, kbeg));
+  const long long step_a = OpA::slab_bytes(p.lda), step_b = OpB::slab_bytes(p.ldb);
+  if constexpr (FULL) {
+    OpA::lane_offsets(p.lda, offa);
+    OpB::lane_offsets(p.ldb, offb);
+  }
+// (a macro rather than a lambda: arrays captured by reference end up in scratch memory)
+#define VITK_FETCH(T)                                                                                       \
+  if constexpr (FULL) {                                                                                     \
+    _Pragma("unroll") for (int it = 0; it < OpA::NL; ++it) ra[it] =                                         \
+        *reinterpret_cast<const f32x4 *>(pa + offa[it]);                                                   \
+    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) rb[it] =                                         \
+        *reinterpret_cast<const f32x4 *>(pb + offb[it]);                                                   \
+    pa += step_a;                                                                                           \
+    pb += step_b;                                                                                           \
+  } else {                                                                                                  \
+    OpA::load(A, p.lda, m0, p.M, kbeg + (T)*BK, kend, va, ra);                                              \
+    OpB::load(B, p.ldb, n0, p.N, kbeg + (T)*BK, kend, vb, rb);                                              \
+  }
   if (nslab > 0) {
-    OpA::load(A, p.lda, m0, p.M, kbeg, kend, va, ra);
-    OpB::load(B, p.ldb, n0, p.N, kbeg, kend, vb, rb);
+    VITK_FETCH(0)
     OpA::store(As[0], ra);
     OpB::store(Bs[0], rb);
   }
@@ -185,22 +234,34 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const Params p) {
   for (int t = 0; t < nslab; ++t) {
     const int cur = t & 1;
     if (t + 1 < nslab) {
-      OpA::load(A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, va, ra);
-      OpB::load(B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, vb, rb);
+      VITK_FETCH(t + 1)
     }
-    const float *__restrict__ as = As[cur] + wr * WT + li;
-    const float *__restrict__ bs = Bs[cur] + wc * WT + li;
+    const float *__restrict__ as = As[cur] + wr * WT + li + lh * OpA::LD;
+    const float *__restrict__ bs = Bs[cur] + wc * WT + li + lh * OpB::LD;
+    // Operand reads run one k-step ahead of the MFMAs that consume them (two register sets), and
+    // the scheduler is pinned to that order: hoisting all 32 reads of a slab would cost 32 extra
+    // registers, push the global prefetch registers into scratch and serialise on their loads.
+    float a[2][NT], b[2][NT];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[NT], b[NT];
+    for (int i = 0; i < NT; ++i) a[0][i] = as[i * 32];
 #pragma unroll
-      for (int i = 0; i < NT; ++i) a[i] = as[(kk + lh) * OpA::LD + i * 32];
+    for (int j = 0; j < NT; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = bs[(kk + lh) * OpB::LD + j * 32];
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int c = ks & 1, n = c ^ 1;
+      if (ks + 1 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) a[n][i] = as[(2 * ks + 2) * OpA::LD + i * 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[n][j] = bs[(2 * ks + 2) * OpB::LD + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);   // the next step's LDS reads ...
+      __builtin_amdgcn_sched_group_barrier(0x008, NT * NT, 0);  // ... then this step's MFMAs
     }
     if (t + 1 < nslab) {
       OpA::store(As[cur ^ 1], ra);
@@ -208,47 +269,64 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const Params p) {
     }
     __syncthreads();
   }
+#undef VITK_FETCH
 
   // Epilogue.  Accumulator register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its
   // 32x32 tile: per register, lanes 0-31 and 32-63 each write one 128-byte row segment.
+  // Addresses are a uniform per-register base plus one per-lane byte offset per pitch, so the 64
+  // stores (and the residual / pre-activation loads) cost no vector registers for addressing.
+  const int row_w = m0 + wr * WT, col_w = n0 + wc * WT;  // this wave's sub-tile origin
   if (p.split_k > 1) {
-    float *__restrict__ W = p.ws + (long long)z * p.M * p.N;
+    char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
+    const unsigned lane_w = (unsigned)((4 * lh * (long long)p.N + li) * 4);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wc * WT + j * 32 + li;
+        const int col = col_w + j * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wr * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < p.M && col < p.N) W[(long long)row * p.N + col] = acc[i][j][r];
+          const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+          const int row = row_w + dr + 4 * lh;
+          if (FULL || (row < p.M && col < p.N))
+            *reinterpret_cast<float *>(W + ((long long)dr * p.N + j * 32) * 4 + lane_w) = acc[i][j][r];
         }
       }
     return;
   }
 
-  float *__restrict__ C = p.C + bo * p.sc_o + bi * p.sc_i;
+  char *C = reinterpret_cast<char *>(p.C + bo * p.sc_o + bi * p.sc_i + (long long)row_w * p.ldc + col_w);
+  const char *R = reinterpret_cast<const char *>(p.residual ? p.residual + (long long)row_w * p.ldr + col_w : nullptr);
+  char *X = reinterpret_cast<char *>(p.aux ? p.aux + (long long)row_w * p.ldaux + col_w : nullptr);
+  const unsigned lane_c = (unsigned)((4 * lh * p.ldc + li) * 4);
+  const unsigned lane_r = (unsigned)((4 * lh * p.ldr + li) * 4);
+  const unsigned lane_x = (unsigned)((4 * lh * p.ldaux + li) * 4);
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int col = n0 + wc * WT + j * 32 + li;
-      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+      const int col = col_w + j * 32 + li;
+      const float bv = (p.bias != nullptr && (FULL || col < p.N)) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M && col < p.N) {
+        const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+        const int row = row_w + dr + 4 * lh;
+        if (FULL || (row < p.M && col < p.N)) {
           float v = p.alpha * acc[i][j][r];
-          if (p.act == VITK_ACT_GELU_BWD) v *= vitk::gelu_grad(p.aux[(long long)row * p.ldaux + col]);
+          float *xp = reinterpret_cast<float *>(X + ((long long)dr * p.ldaux + j * 32) * 4 + lane_x);
+          if (p.act == VITK_ACT_GELU_BWD) v *= vitk::gelu_grad(*xp);
           v += bv;
           if (p.act == VITK_ACT_GELU_FWD) {
-            if (p.aux != nullptr) p.aux[(long long)row * p.ldaux + col] = v;
+            if (p.aux != nullptr) *xp = v;
             v = vitk::gelu_fwd(v);
           }
-          if (p.residual != nullptr) v += p.residual[(long long)row * p.ldr + col];
-          C[(long long)row * p.ldc + col] = v;
+          if (p.residual != nullptr)
+            v += *reinterpret_cast<const float *>(R + ((long long)dr * p.ldr + j * 32) * 4 + lane_r);
+          *reinterpret_cast<float *>(C + ((long long)dr * p.ldc + j * 32) * 4 + lane_c) = v;
         }
       }
+      // keep the loads of one 32x32 tile from being hoisted above the stores of the previous one
+      asm volatile("" ::: "memory");
     }
 }
 
@@ -273,10 +351,14 @@ struct Plan {
 };
 
 int choose_split(long long tiles, int K) {
-  // Fill the chip (256 CUs, a few workgroups each) when the output has too few tiles -- the
-  // weight-gradient GEMMs contract over all B*N token rows into a small [in][out] matrix.
-  if (tiles >= 256) return 1;
-  long long want = (768 + tiles - 1) / tiles;
+  // Weight-gradient GEMMs contract over all B*N token rows into a small [in][out] matrix: too few
+  // output tiles to occupy 256 CUs.  Split the contraction so that tiles*splits comes just under
+  // one full round of resident workgroups (256 CUs x kBlocksPerCU): every workgroup then runs
+  // concurrently and they all finish together -- a second, mostly empty round would cost as much
+  // as the first.
+  const long long slots = 256 * kBlocksPerCU;
+  if (tiles >= slots / 2) return 1;
+  long long want = slots / tiles;
   long long max_by_k = K / (8 * BK);
   if (max_by_k < 1) max_by_k = 1;
   if (want > max_by_k) want = max_by_k;
@@ -309,12 +391,18 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
   return 0;
 }
 
+template <int TILE, bool FULL>
+void launch2(const Params &p, bool ta, bool tb, dim3 grid, hipStream_t st) {
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, false, FULL>), grid, dim3(THREADS), 0, st, p);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, true, FULL>), grid, dim3(THREADS), 0, st, p);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, true, false, FULL>), grid, dim3(THREADS), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<TILE, true, true, FULL>), grid, dim3(THREADS), 0, st, p);
+}
+
 template <int TILE>
-void launch(const Params &p, bool ta, bool tb, dim3 grid, hipStream_t st) {
-  if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, false>), grid, dim3(THREADS), 0, st, p);
-  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, true>), grid, dim3(THREADS), 0, st, p);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, true, false>), grid, dim3(THREADS), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<TILE, true, true>), grid, dim3(THREADS), 0, st, p);
+void launch(const Params &p, bool ta, bool tb, bool full, dim3 grid, hipStream_t st) {
+  if (full) launch2<TILE, true>(p, ta, tb, grid, st);
+  else launch2<TILE, false>(p, ta, tb, grid, st);
 }
 
 bool strides_vec_ok(const float *p, long long ld, long long so, long long si) {
@@ -344,7 +432,9 @@ hipEvent_t prof_event() {
   return e;
 }
 
-int variant_of(int tile, bool ta, bool tb) { return (tile == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0); }
+int variant_of(int tile, bool ta, bool tb, bool full) {
+  return (full ? 8 : 0) + (tile == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0);
+}
 
 }  // namespace
 
@@ -396,16 +486,20 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
 
   hipStream_t st = vitk::as_stream(stream);
   dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)(pl.batch * pl.split_k), 1);
+  // every K chunk starts and ends on a slab boundary when K and the chunk are multiples of BK
+  const bool full = p.vec_a && p.vec_b && a->M % pl.tile == 0 && a->N % pl.tile == 0 && a->K > 0 &&
+                    a->K % BK == 0 && pl.k_chunk % BK == 0 && a->lda < (1 << 21) && a->ldb < (1 << 21) &&
+                    a->ldc < (1 << 21) && a->ldr < (1 << 21) && a->ldaux < (1 << 21);
   ProfRec rec{};
   if (g_prof_on) {
-    rec.variant = variant_of(pl.tile, a->trans_a != 0, a->trans_b != 0);
+    rec.variant = variant_of(pl.tile, a->trans_a != 0, a->trans_b != 0, full);
     rec.flops = 2.0 * a->M * a->N * a->K * pl.batch;
     rec.e0 = prof_event();
     rec.e1 = prof_event();
     (void)hipEventRecord(rec.e0, st);
   }
-  if (pl.tile == 128) launch<128>(p, a->trans_a != 0, a->trans_b != 0, grid, st);
-  else launch<64>(p, a->trans_a != 0, a->trans_b != 0, grid, st);
+  if (pl.tile == 128) launch<128>(p, a->trans_a != 0, a->trans_b != 0, full, grid, st);
+  else launch<64>(p, a->trans_a != 0, a->trans_b != 0, full, grid, st);
   if (g_prof_on) {
     (void)hipEventRecord(rec.e1, st);
     g_prof.push_back(rec);
@@ -427,7 +521,7 @@ extern "C" int vitk_gemm_profile_enable(int on) {
 
 extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *total_flops, int64_t *launches,
                                       int reset) {
-  VITK_REQUIRE(variant >= 0 && variant < 8, "vitk_gemm_profile_read: variant %d outside [0,8)", variant);
+  VITK_REQUIRE(variant >= 0 && variant < 16, "vitk_gemm_profile_read: variant %d outside [0,16)", variant);
   double ms = 0.0, fl = 0.0;
   int64_t n = 0;
   for (const ProfRec &r : g_prof) {
@@ -455,9 +549,14 @@ extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *tot
 }
 
 extern "C" const char *vitk_gemm_variant_name(int variant) {
-  static const char *names[8] = {
-      "gemm_kernel<128, false, false>", "gemm_kernel<128, false, true>", "gemm_kernel<128, true, false>",
-      "gemm_kernel<128, true, true>",   "gemm_kernel<64, false, false>", "gemm_kernel<64, false, true>",
-      "gemm_kernel<64, true, false>",   "gemm_kernel<64, true, true>"};
-  return (variant >= 0 && variant < 8) ? names[variant] : "";
+  static const char *names[16] = {
+      "gemm_kernel<128, false, false, false>", "gemm_kernel<128, false, true, false>",
+      "gemm_kernel<128, true, false, false>",  "gemm_kernel<128, true, true, false>",
+      "gemm_kernel<64, false, false, false>",  "gemm_kernel<64, false, true, false>",
+      "gemm_kernel<64, true, false, false>",   "gemm_kernel<64, true, true, false>",
+      "gemm_kernel<128, false, false, true>",  "gemm_kernel<128, false, true, true>",
+      "gemm_kernel<128, true, false, true>",   "gemm_kernel<128, true, true, true>",
+      "gemm_kernel<64, false, false, true>",   "gemm_kernel<64, false, true, true>",
+      "gemm_kernel<64, true, false, true>",    "gemm_kernel<64, true, true, true>"};
+  return (variant >= 0 && variant < 16) ? names[variant] : "";
 }
