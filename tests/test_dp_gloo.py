@@ -1,0 +1,126 @@
+"""Data-parallel driver (visiontransformer_amd/dp.py) with world size 2 over gloo on CPU.
+
+The GPU engine cannot run here, so a stand-in engine with the same protocol computes each
+rank's gradients with the CPU oracle (checker code, test-only) into a flat torch tensor; the
+driver under test does the sharding arithmetic (global-batch scaling), the bucket plan, the
+asynchronous per-bucket all-reduces, the parameter broadcast and the update order.  Expected
+result: both ranks end bit-identical and equal to single-process oracle training on the whole
+batch (to fp32 reduction-order noise)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import vitlibs as V  # noqa: E402
+from visiontransformer_amd import dp  # noqa: E402
+
+CFG = V.TINY
+B_GLOBAL, STEPS = 8, 3
+
+
+class OracleEngine:
+    """CPU stand-in: same protocol as dp.HostEngine, gradients from the oracle at stage 0."""
+
+    def __init__(self, seed):
+        self.O = V.oracle()
+        self.cfg = V.Cfg.make(**CFG)
+        self.n = self.O.vo_param_count(self.cfg)
+        self.params = torch.from_numpy(V.init_params(self.cfg, seed))
+        self.grads = torch.zeros(self.n)
+        self.m, self.v = np.zeros(self.n, np.float32), np.zeros(self.n, np.float32)
+        self.t = 0
+        # stage slices in the device arena's order: head+final norm, blocks last..first, embeddings
+        c, D, H = self.cfg, self.cfg.embedding_dim, self.cfg.mlp_hidden_dim
+        emb = c.patch_dim * D + 2 * D + c.tokens * D
+        blk = 4 * D + 4 * (D * D + D) + 2 * D * H + H + D
+        tail = 2 * D + D * c.num_classes + c.num_classes
+        offs = [0, emb] + [emb + blk * (i + 1) for i in range(c.num_layers)] + [emb + blk * c.num_layers + tail]
+        self.ranges = [(offs[-2], tail)] + [(offs[i], blk) for i in range(c.num_layers, 0, -1)] + [(0, emb)]
+        self.num_stages = len(self.ranges)
+
+    def stage_grad_range(self, s):
+        return self.ranges[s]
+
+    def step_forward(self, x, y, grad_batch):
+        self._x, self._y, self._scale = x.numpy(), y.numpy(), x.shape[0] / grad_batch
+
+    def backward_stage(self, s):
+        if s == 0:  # the oracle computes everything at once; later stages have nothing left to do
+            g = V.f32(self.n)
+            self.loss = self.O.vo_forward_backward(self.cfg, self.params.numpy(), self._x, self._y, self._x.shape[0],
+                                                   None, 0, None, g, None)
+            self.grads.copy_(torch.from_numpy(g * np.float32(self._scale)))
+
+    def update(self, lr, grad_scale):
+        self.t += 1
+        b1t = float(np.float32(np.float64(np.float32(0.9)) ** self.t))
+        b2t = float(np.float32(np.float64(np.float32(0.999)) ** self.t))
+        p = self.params.numpy()
+        self.O.vo_adam_update(p, (self.grads * grad_scale).numpy(), self.m, self.v, self.n, lr, 0.9, 0.999, b1t, b2t,
+                              1e-8, 1e-4)
+
+
+def batches():
+    cfg = V.Cfg.make(**CFG)
+    xs = [V.rng_normal(10 + s, B_GLOBAL, 1, 28, 28) for s in range(STEPS)]
+    ys = [V.onehot(np.random.default_rng(20 + s).integers(0, 10, B_GLOBAL), 10) for s in range(STEPS)]
+    return cfg, xs, ys
+
+
+def worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = OracleEngine(seed=100 + rank)  # different init per rank: the broadcast must fix that
+    ddp = dp.DataParallel(eng, bucket_bytes=16 << 10)  # small buckets => several collectives per step
+    assert len(ddp.buckets) > 1
+    ddp.broadcast_parameters(0)
+    _, xs, ys = batches()
+    sh = B_GLOBAL // world
+    for s in range(STEPS):
+        x, y = torch.from_numpy(xs[s][rank * sh:(rank + 1) * sh]), torch.from_numpy(ys[s][rank * sh:(rank + 1) * sh])
+        ddp.step(x, y, 1e-3)
+    out[rank] = eng.params.clone()
+    dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bucket_plan_covers_the_arena_once():
+    eng = OracleEngine(1)
+    for bb in (1, 16 << 10, 1 << 30):
+        plan = dp.plan_buckets(eng.ranges, bb)
+        covered = sorted((o, o + c) for _, o, c in plan)
+        assert covered[0][0] == 0 and covered[-1][1] == eng.n
+        for (a, b), (c, d) in zip(covered[:-1], covered[1:]):
+            assert b == c
+        assert [s for s, _, _ in plan] == sorted(s for s, _, _ in plan)
+    assert len(dp.plan_buckets(eng.ranges, 1 << 30)) == 1
+    assert len(dp.plan_buckets(eng.ranges, 1)) == eng.num_stages
+
+
+def test_two_rank_gloo_matches_single_process_training():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(worker, args=(world, free_port(), out), nprocs=world, join=True)
+    p0, p1 = out[0].numpy(), out[1].numpy()
+    np.testing.assert_array_equal(p0, p1)  # replicas stay bit-identical
+    # single process, whole batch
+    eng = OracleEngine(seed=100)
+    single = dp.DataParallel(eng)
+    assert single.world == 1
+    _, xs, ys = batches()
+    for s in range(STEPS):
+        single.step(torch.from_numpy(xs[s]), torch.from_numpy(ys[s]), 1e-3)
+    ref = eng.params.numpy()
+    assert V.max_relerr(p0, ref) <= 2e-6, V.max_relerr(p0, ref)

@@ -203,17 +203,28 @@ __global__ void ln_param_grad_generic(const float *__restrict__ dy, const float 
   }
 }
 
-__global__ void ln_param_grad_final(const float *__restrict__ partial, int nblk, int D, float *__restrict__ dgamma,
-                                    float *__restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    a += partial[((long long)k * 2 + 0) * D + c];
-    b += partial[((long long)k * 2 + 1) * D + c];
+// Second stage of every cross-row reduction in this file: out[c] = sum_k partial[k*pitch + c] for
+// k in [0, n), in a fixed order.  A workgroup owns 64 columns; its 4 waves each sum every fourth
+// partial row (coalesced 256-byte reads) and the four sums are combined through LDS.
+constexpr int RED_COLS = 64;
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int n,
+                                                              long long pitch, long long cols,
+                                                              float *__restrict__ out) {
+  __shared__ float sm[4][RED_COLS];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long c = (long long)blockIdx.x * RED_COLS + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int k = g;
+    for (; k + 4 < n; k += 8) {
+      s0 += partial[(long long)k * pitch + c];
+      s1 += partial[(long long)(k + 4) * pitch + c];
+    }
+    if (k < n) s0 += partial[(long long)k * pitch + c];
   }
-  dgamma[c] = a;
-  dbeta[c] = b;
+  sm[g][lane] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && c < cols) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 // ---- column sum -------------------------------------------------------------------------------
@@ -235,17 +246,9 @@ __global__ void colsum_stage1(const float *__restrict__ x, long long rows, long 
   partial[blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
 }
 
-__global__ void colsum_stage2(const float *__restrict__ partial, int nchunks, long long cols, float *__restrict__ out) {
-  const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int k = 0; k < nchunks; ++k) s += partial[k * cols + c];
-  out[c] = s;
-}
-
 int ln_blocks(long long rows) {
   long long b = (rows + WPB - 1) / WPB;
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -255,7 +258,7 @@ void colsum_plan(long long rows, long long cols, int *nchunks, long long *rpc) {
   long long n = 2048 / colblocks;
   const long long maxn = (rows + 31) / 32;
   if (n > maxn) n = maxn;
-  if (n > 1024) n = 1024;
+  if (n > 256) n = 256;
   if (n < 1) n = 1;
   *rpc = (rows + n - 1) / n;
   *nchunks = (int)((rows + *rpc - 1) / *rpc);
@@ -297,7 +300,8 @@ int vitk_colsum_f32(const float *x, int64_t rows, int64_t cols, int64_t ldx, flo
   hipLaunchKernelGGL(colsum_stage1, dim3(cb, (unsigned)n), dim3(256), 0, st, x, (long long)rows, (long long)cols,
                      (long long)ldx, rpc, workspace);
   if (vitk::check_launch("vitk_colsum_f32/stage1")) return 1;
-  hipLaunchKernelGGL(colsum_stage2, dim3(cb), dim3(256), 0, st, workspace, n, (long long)cols, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cols + RED_COLS - 1) / RED_COLS)), dim3(256), 0, st,
+                     workspace, n, (long long)cols, (long long)cols, out);
   return vitk::check_launch("vitk_colsum_f32/stage2");
 }
 
@@ -364,8 +368,11 @@ int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const
   }
 #undef LNB
   if (vitk::check_launch("vitk_layernorm_bwd")) return 1;
-  hipLaunchKernelGGL(ln_param_grad_final, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, workspace, nblk, (int)D,
-                     dgamma, dbeta);
+  const dim3 rg((unsigned)((D + RED_COLS - 1) / RED_COLS));
+  hipLaunchKernelGGL(reduce_partials_kernel, rg, dim3(256), 0, st, workspace, nblk, (long long)(2 * D), (long long)D,
+                     dgamma);
+  hipLaunchKernelGGL(reduce_partials_kernel, rg, dim3(256), 0, st, workspace + D, nblk, (long long)(2 * D),
+                     (long long)D, dbeta);
   return vitk::check_launch("vitk_layernorm_bwd/final");
 }
 
