@@ -4,9 +4,10 @@
 // Structure of one workgroup (256 threads = 4 waves, one per SIMD, arranged 2 x 2):
 //   * output tile TILE x TILE (128 or 64); each wave owns a (TILE/2)^2 sub-tile = NT x NT MFMA tiles
 //     of 32x32, accumulators live in registers for the whole K loop;
-//   * the K loop walks BK = 16 deep slabs.  Slab t+1 is fetched global->registers (16-byte loads)
-//     while slab t is consumed from LDS; it is written to the other LDS buffer after the MFMAs, so
-//     there is one barrier per slab and global latency hides behind 8 x NT^2 MFMAs per wave;
+//   * the K loop walks BK = 16 deep slabs through a three-slot LDS ring: while slab t is multiplied,
+//     slab t+2 moves registers->LDS and slab t+3 global->registers (16-byte loads); the one barrier
+//     per slab sits in the middle of the slab's MFMAs, so operand reads never wait at a slab
+//     boundary and global latency hides behind more than a slab of MFMAs;
 //   * both operands sit in LDS as [k][m|n] so that an MFMA operand read is one conflict-free
 //     ds_read_b32 per lane (lane l reads element [k0 + l/32][i0 + l%32]).  Operands whose
 //     contraction index is contiguous in memory are transposed on the LDS write; the row pitch
@@ -25,6 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 constexpr int THREADS = 256;
+constexpr int STAGES = 3;  // LDS ring depth (slabs)
 // Workgroups resident per CU (= waves per SIMD) the kernels are compiled for; the split-K plan
 // sizes its grid to one full round of these.
 constexpr int kBlocksPerCU = 3;
@@ -50,7 +52,53 @@ struct Params {
   float *ws;
   int tiles_m, tiles_n;
   int vec_a, vec_b;
+#ifdef VITK_GEMM_STAMPS
+  unsigned long long *stamps;  // diagnostic build only: 8 clock stamps per workgroup
+  int skip_store;              // diagnostic build only: run everything but the epilogue's stores
+#endif
 };
+// Diagnostic build (-DVITK_GEMM_STAMPS, tools/gemm_stamps.py): thread 0 of every workgroup records
+// shader-clock stamps at kernel start (0), loop start (1), loop end (2), kernel end (3), its
+// HW_ID register (4) and the 100 MHz wall clock at start (5) and end (7).
+#ifdef VITK_GEMM_STAMPS
+#define VITK_STAMP_SLOT(i) p.stamps[(blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) * 16 + (i)]
+#define VITK_STAMP(i) \
+  if (p.stamps != nullptr && threadIdx.x == 0) VITK_STAMP_SLOT(i) = __builtin_amdgcn_s_memtime();
+#define VITK_STAMP_AUX()                                               \
+  if (p.stamps != nullptr && threadIdx.x == 0) {                       \
+    VITK_STAMP_SLOT(4) = __builtin_amdgcn_s_getreg((31 << 11) | 4);    \
+    VITK_STAMP_SLOT(5) = __builtin_amdgcn_s_memrealtime();             \
+  }
+#define VITK_STAMP_END() \
+  if (p.stamps != nullptr && threadIdx.x == 0) VITK_STAMP_SLOT(7) = __builtin_amdgcn_s_memrealtime();
+#else
+#define VITK_STAMP(i)
+#define VITK_STAMP_AUX()
+#define VITK_STAMP_END()
+#endif
+#ifdef VITK_GEMM_STAMPS
+#define VITK_DIAG_KEEP(bit) (!(p.skip_store & (bit)))  // diagnostic build: knock out one phase (wrong results)
+#else
+#define VITK_DIAG_KEEP(bit) true
+#endif
+// Level 2: per-slab segment times accumulated into slots 8.. (perturbs the loop; attribution only).
+#if defined(VITK_GEMM_STAMPS) && VITK_GEMM_STAMPS > 1
+#define VITK_SEG_DECL() unsigned long long seg_t = __builtin_amdgcn_s_memtime(), seg_acc[5] = {0, 0, 0, 0, 0};
+#define VITK_SEG(i)                                             \
+  {                                                             \
+    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    seg_acc[i] += now - seg_t;                                  \
+    seg_t = now;                                                \
+  }
+#define VITK_SEG_FLUSH()                           \
+  if (p.stamps != nullptr && threadIdx.x == 0) {   \
+    for (int q = 0; q < 5; ++q) VITK_STAMP_SLOT(8 + q) = seg_acc[q]; \
+  }
+#else
+#define VITK_SEG_DECL()
+#define VITK_SEG(i)
+#define VITK_SEG_FLUSH()
+#endif
 
 // Operand whose contraction index k is contiguous in memory: element (row, k) at base[row*ld + k].
 // Thread q handles row r = q / (BK/4), k-quad kq = q % (BK/4).
@@ -160,16 +208,24 @@ struct Operand<true, ROWS> : KContig<ROWS> {};
 template <int ROWS>
 struct Operand<false, ROWS> : MnContig<ROWS> {};
 
-// FULL: every tile and every K slab is complete and both operands allow 16-byte loads, so the
-// loop carries no bounds checks at all (true for every large contraction of ViT-Ti/S/B).
+// Workgroup barrier that orders LDS traffic only (waits for this wave's outstanding LDS operations,
+// not for its global prefetch loads, which __syncthreads() would also drain).
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// FULL: every tile and every K slab is complete and all operands allow 16-byte accesses, so the
+// loop and the epilogue carry no bounds checks at all (true for every large contraction of
+// ViT-Ti/S/B).
 template <int TILE, bool TA, bool TB, bool FULL>
 __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Params p) {
   using OpA = Operand<!TA, TILE>;  // A is k-contiguous when not transposed
   using OpB = Operand<TB, TILE>;   // B is k-contiguous when transposed
   constexpr int WT = TILE / 2;     // per-wave tile
   constexpr int NT = WT / 32;      // MFMA tiles per wave per dimension
-  __shared__ __attribute__((aligned(16))) float As[2][BK * OpA::LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * OpB::LD];
+  constexpr int SA = BK * OpA::LD, SB = BK * OpB::LD;
+  __shared__ __attribute__((aligned(16))) float As[STAGES * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[STAGES * SB];
+  VITK_STAMP(0)
+  VITK_STAMP_AUX()
 
   // XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) get a contiguous run of
   // tiles, and consecutive tiles share the A row panel, so panel re-reads hit that XCD's L2.
@@ -200,7 +256,7 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[OpA::NL], rb[OpB::NL];
+  f32x4 ra0[OpA::NL], rb0[OpB::NL], ra1[OpA::NL], rb1[OpB::NL];  // two slabs in flight
   const bool va = p.vec_a, vb = p.vec_b;
   // FULL: uniform tile-origin pointers (scalar registers) + constant per-lane byte offsets
   unsigned offa[OpA::NL], offb[OpB::NL];
@@ -212,122 +268,254 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     OpB::lane_offsets(p.ldb, offb);
   }
 // (a macro rather than a lambda: arrays captured by reference end up in scratch memory)
-#define VITK_FETCH(T)                                                                                       \
+#define VITK_FETCH(T, RA, RB)                                                                               \
   if constexpr (FULL) {                                                                                     \
-    _Pragma("unroll") for (int it = 0; it < OpA::NL; ++it) ra[it] =                                         \
+    _Pragma("unroll") for (int it = 0; it < OpA::NL; ++it) RA[it] =                                         \
         *reinterpret_cast<const f32x4 *>(pa + offa[it]);                                                   \
-    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) rb[it] =                                         \
+    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) RB[it] =                                         \
         *reinterpret_cast<const f32x4 *>(pb + offb[it]);                                                   \
     pa += step_a;                                                                                           \
     pb += step_b;                                                                                           \
   } else {                                                                                                  \
-    OpA::load(A, p.lda, m0, p.M, kbeg + (T)*BK, kend, va, ra);                                              \
-    OpB::load(B, p.ldb, n0, p.N, kbeg + (T)*BK, kend, vb, rb);                                              \
+    OpA::load(A, p.lda, m0, p.M, kbeg + (T)*BK, kend, va, RA);                                              \
+    OpB::load(B, p.ldb, n0, p.N, kbeg + (T)*BK, kend, vb, RB);                                              \
   }
-  if (nslab > 0) {
-    VITK_FETCH(0)
-    OpA::store(As[0], ra);
-    OpB::store(Bs[0], rb);
-  }
-  __syncthreads();
 
-  for (int t = 0; t < nslab; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nslab) {
-      VITK_FETCH(t + 1)
+  // Three-slab LDS ring fed through two register sets.  While slab t is multiplied out of ring
+  // slot t%3, slab t+1 already sits in slot (t+1)%3, slab t+2 moves registers -> slot (t+2)%3 and
+  // slabs t+3, t+4 are in flight global -> registers (two slabs of MFMAs cover the load latency).
+  // The single barrier of a slab sits in its MIDDLE: a wave that has passed it knows every wave
+  // is done with slab t-1 (so its slot may be overwritten) and that slab t+1 is completely
+  // written (so operand reads run across the slab boundary without a stall).
+  const int lane_a = wr * WT + li + lh * OpA::LD, lane_b = wc * WT + li + lh * OpB::LD;
+  int cur = 0;  // ring slot of slab t
+  int t = 0;
+  // Operand reads run one k-step ahead of the MFMAs that consume them (two register sets).
+  float a[2][NT], b[2][NT];
+#define VITK_FIRST_OPERANDS()                                                             \
+  lds_barrier();                                                                          \
+  VITK_STAMP(1)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < NT; ++i) a[0][i] = As[lane_a + i * 32];           \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j) b[0][j] = Bs[lane_b + j * 32];
+
+  // One slab (index T, prefetch registers RA/RB hold slab T+2 on entry, slab T+4 on exit;
+  // STEADY: slabs T+2 and T+4 are known to exist).
+  // On the FULL path the second operand goes into the MFMA as the row operand: the accumulator
+  // tile is C^T, i.e. each lane ends up with runs of 4 consecutive columns of one row of C
+  // (16-byte stores); the guarded path keeps plain accumulators (row-segment stores, any edge).
+#define VITK_SLAB(T, RA, RB, STEADY)                                                                                \
+  {                                                                                                         \
+    const int nxt = cur == STAGES - 1 ? 0 : cur + 1;                                                        \
+    const int fre = nxt == STAGES - 1 ? 0 : nxt + 1;                                                        \
+    const float *__restrict__ as = As + cur * SA + lane_a;                                                  \
+    const float *__restrict__ bs = Bs + cur * SB + lane_b;                                                  \
+    const float *__restrict__ as_n = As + nxt * SA + lane_a;                                                \
+    const float *__restrict__ bs_n = Bs + nxt * SB + lane_b;                                                \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                                                 \
+      const int c = ks & 1, n = c ^ 1;                                                                      \
+      if (ks + 1 < BK / 2) {                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) a[n][i] = as[(2 * ks + 2) * OpA::LD + i * 32];       \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) b[n][j] = bs[(2 * ks + 2) * OpB::LD + j * 32];       \
+      } else { /* first k-step of the next slab (after the last slab: a harmless stale read) */             \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) a[n][i] = as_n[i * 32];                              \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) b[n][j] = bs_n[j * 32];                              \
+      }                                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < NT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)         \
+          acc[i][j] = FULL ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[c][j], a[c][i], acc[i][j], 0, 0, 0)     \
+                           : __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);    \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);  /* the next step's LDS reads ... */          \
+      __builtin_amdgcn_sched_group_barrier(0x008, NT * NT, 0); /* ... then this step's MFMAs */             \
+      if (ks == BK / 4 - 1) {                                                                               \
+        VITK_SEG(0)                                                                                         \
+        lds_barrier();                                                                                      \
+        VITK_SEG(1)                                                                                         \
+        if ((STEADY || (T) + 2 < nslab) && VITK_DIAG_KEEP(2)) {                                             \
+          OpA::store(As + fre * SA, RA);                                                                    \
+          OpB::store(Bs + fre * SB, RB);                                                                    \
+        }                                                                                                   \
+        VITK_SEG(2)                                                                                         \
+        if ((STEADY || (T) + 4 < nslab) && VITK_DIAG_KEEP(4)) {                                             \
+          VITK_FETCH((T) + 4, RA, RB)                                                                       \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0); /* keep the loads here: sunk below the MFMAs they lose cover */ \
+        VITK_SEG(3)                                                                                         \
+      }                                                                                                     \
+    }                                                                                                       \
+    VITK_SEG(4)                                                                                             \
+    cur = nxt;                                                                                              \
+  }
+
+  VITK_SEG_DECL()
+  // Long contractions: a straight-line prologue and a condition-free steady state in ONE branch,
+  // so the compiler counts the loads in flight exactly and a slab waits only for the older of
+  // the two register sets.  Everything else (short contractions, the last slabs) takes the
+  // guarded path below.
+  if (nslab >= 6) {
+    VITK_FETCH(0, ra0, rb0)
+    OpA::store(As, ra0);
+    OpB::store(Bs, rb0);
+    VITK_FETCH(1, ra1, rb1)
+    OpA::store(As + SA, ra1);
+    OpB::store(Bs + SB, rb1);
+    VITK_FETCH(2, ra0, rb0)
+    VITK_FETCH(3, ra1, rb1)
+    VITK_FIRST_OPERANDS()
+    for (; t + 5 < nslab; t += 2) {
+      VITK_SLAB(t, ra0, rb0, true)
+      VITK_SLAB(t + 1, ra1, rb1, true)
     }
-    const float *__restrict__ as = As[cur] + wr * WT + li + lh * OpA::LD;
-    const float *__restrict__ bs = Bs[cur] + wc * WT + li + lh * OpB::LD;
-    // Operand reads run one k-step ahead of the MFMAs that consume them (two register sets), and
-    // the scheduler is pinned to that order: hoisting all 32 reads of a slab would cost 32 extra
-    // registers, push the global prefetch registers into scratch and serialise on their loads.
-    float a[2][NT], b[2][NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) a[0][i] = as[i * 32];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b[0][j] = bs[j * 32];
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int c = ks & 1, n = c ^ 1;
-      if (ks + 1 < BK / 2) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i) a[n][i] = as[(2 * ks + 2) * OpA::LD + i * 32];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b[n][j] = bs[(2 * ks + 2) * OpB::LD + j * 32];
-      }
+  } else {
+    if (nslab > 0) {
+      VITK_FETCH(0, ra0, rb0)
+      OpA::store(As, ra0);
+      OpB::store(Bs, rb0);
+    }
+    if (nslab > 1) {
+      VITK_FETCH(1, ra1, rb1)
+      OpA::store(As + SA, ra1);
+      OpB::store(Bs + SB, rb1);
+    }
+    if (nslab > 2) {
+      VITK_FETCH(2, ra0, rb0)
+    }
+    if (nslab > 3) {
+      VITK_FETCH(3, ra1, rb1)
+    }
+    VITK_FIRST_OPERANDS()
+  }
+  for (; t < nslab; t += 2) {
+    VITK_SLAB(t, ra0, rb0, false)
+    if (t + 1 < nslab) VITK_SLAB(t + 1, ra1, rb1, false)
+  }
+  VITK_SEG_FLUSH()
+#undef VITK_SLAB
+#undef VITK_FIRST_OPERANDS
+#undef VITK_FETCH
+  VITK_STAMP(2)
+
+  const int row_w = m0 + wr * WT, col_w = n0 + wc * WT;  // this wave's sub-tile origin
+#ifdef VITK_GEMM_STAMPS
+  if ((p.skip_store & 1) && acc[0][0][0] != 12345.678f) {
+    VITK_STAMP(3)
+    VITK_STAMP_END()
+    return;
+  }
+#endif
+  // Epilogue.  Addresses are a uniform base plus one per-lane byte offset per pitch, so the
+  // stores (and the residual / pre-activation loads) cost no vector registers for addressing.
+  if constexpr (FULL) {
+    // Transposed accumulators: registers 4g..4g+3 of lane l hold C[l&31][8g + 4*(l>>5) + 0..3] of
+    // the 32x32 tile -- one 16-byte store per lane and g.
+    if (p.split_k > 1) {
+      char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
+      const unsigned lane_w = (unsigned)((li * (long long)p.N + 4 * lh) * 4);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);   // the next step's LDS reads ...
-      __builtin_amdgcn_sched_group_barrier(0x008, NT * NT, 0);  // ... then this step's MFMAs
-    }
-    if (t + 1 < nslab) {
-      OpA::store(As[cur ^ 1], ra);
-      OpB::store(Bs[cur ^ 1], rb);
-    }
-    __syncthreads();
-  }
-#undef VITK_FETCH
-
-  // Epilogue.  Accumulator register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its
-  // 32x32 tile: per register, lanes 0-31 and 32-63 each write one 128-byte row segment.
-  // Addresses are a uniform per-register base plus one per-lane byte offset per pitch, so the 64
-  // stores (and the residual / pre-activation loads) cost no vector registers for addressing.
-  const int row_w = m0 + wr * WT, col_w = n0 + wc * WT;  // this wave's sub-tile origin
-  if (p.split_k > 1) {
-    char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
-    const unsigned lane_w = (unsigned)((4 * lh * (long long)p.N + li) * 4);
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = col_w + j * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-          const int row = row_w + dr + 4 * lh;
-          if (FULL || (row < p.M && col < p.N))
-            *reinterpret_cast<float *>(W + ((long long)dr * p.N + j * 32) * 4 + lane_w) = acc[i][j][r];
-        }
-      }
-    return;
-  }
-
-  char *C = reinterpret_cast<char *>(p.C + bo * p.sc_o + bi * p.sc_i + (long long)row_w * p.ldc + col_w);
-  const char *R = reinterpret_cast<const char *>(p.residual ? p.residual + (long long)row_w * p.ldr + col_w : nullptr);
-  char *X = reinterpret_cast<char *>(p.aux ? p.aux + (long long)row_w * p.ldaux + col_w : nullptr);
-  const unsigned lane_c = (unsigned)((4 * lh * p.ldc + li) * 4);
-  const unsigned lane_r = (unsigned)((4 * lh * p.ldr + li) * 4);
-  const unsigned lane_x = (unsigned)((4 * lh * p.ldaux + li) * 4);
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = col_w + j * 32 + li;
-      const float bv = (p.bias != nullptr && (FULL || col < p.N)) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-        const int row = row_w + dr + 4 * lh;
-        if (FULL || (row < p.M && col < p.N)) {
-          float v = p.alpha * acc[i][j][r];
-          float *xp = reinterpret_cast<float *>(X + ((long long)dr * p.ldaux + j * 32) * 4 + lane_x);
-          if (p.act == VITK_ACT_GELU_BWD) v *= vitk::gelu_grad(*xp);
-          v += bv;
-          if (p.act == VITK_ACT_GELU_FWD) {
-            if (p.aux != nullptr) *xp = v;
-            v = vitk::gelu_fwd(v);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            *reinterpret_cast<f32x4 *>(W + ((long long)(i * 32) * p.N + j * 32 + 8 * g) * 4 + lane_w) = v;
           }
-          if (p.residual != nullptr)
-            v += *reinterpret_cast<const float *>(R + ((long long)dr * p.ldr + j * 32) * 4 + lane_r);
-          *reinterpret_cast<float *>(C + ((long long)dr * p.ldc + j * 32) * 4 + lane_c) = v;
+    } else {
+      char *C = reinterpret_cast<char *>(p.C + bo * p.sc_o + bi * p.sc_i + (long long)row_w * p.ldc + col_w);
+      const char *R =
+          reinterpret_cast<const char *>(p.residual ? p.residual + (long long)row_w * p.ldr + col_w : nullptr);
+      char *X = reinterpret_cast<char *>(p.aux ? p.aux + (long long)row_w * p.ldaux + col_w : nullptr);
+      const unsigned lane_c = (unsigned)((li * p.ldc + 4 * lh) * 4);
+      const unsigned lane_r = (unsigned)((li * p.ldr + 4 * lh) * 4);
+      const unsigned lane_x = (unsigned)((li * p.ldaux + 4 * lh) * 4);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = col_w + j * 32 + 8 * g + 4 * lh;
+            f32x4 *cp = reinterpret_cast<f32x4 *>(C + ((long long)(i * 32) * p.ldc + j * 32 + 8 * g) * 4 + lane_c);
+            f32x4 *xp = reinterpret_cast<f32x4 *>(X + ((long long)(i * 32) * p.ldaux + j * 32 + 8 * g) * 4 + lane_x);
+            const f32x4 *rp =
+                reinterpret_cast<const f32x4 *>(R + ((long long)(i * 32) * p.ldr + j * 32 + 8 * g) * 4 + lane_r);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, xv = bv, rv = bv, v, pre;
+            if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(p.bias + col);
+            if (p.act == VITK_ACT_GELU_BWD) xv = *xp;
+            if (p.residual != nullptr) rv = *rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float y = p.alpha * acc[i][j][4 * g + e];
+              if (p.act == VITK_ACT_GELU_BWD) y *= vitk::gelu_grad(xv[e]);
+              y += bv[e];
+              pre[e] = y;
+              if (p.act == VITK_ACT_GELU_FWD) y = vitk::gelu_fwd(y);
+              if (p.residual != nullptr) y += rv[e];
+              v[e] = y;
+            }
+            if (p.act == VITK_ACT_GELU_FWD && p.aux != nullptr) *xp = pre;
+            *cp = v;
+          }
+          // keep the loads of one 32x32 tile from being hoisted above the stores of the previous one
+          asm volatile("" ::: "memory");
         }
-      }
-      // keep the loads of one 32x32 tile from being hoisted above the stores of the previous one
-      asm volatile("" ::: "memory");
     }
+  } else {
+    // Plain accumulators: register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of the
+    // 32x32 tile -- per register, lanes 0-31 and 32-63 each write one 128-byte row segment (any
+    // alignment, any edge).
+    if (p.split_k > 1) {
+      char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
+      const unsigned lane_w = (unsigned)((4 * lh * (long long)p.N + li) * 4);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = col_w + j * 32 + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+            const int row = row_w + dr + 4 * lh;
+            if (row < p.M && col < p.N)
+              *reinterpret_cast<float *>(W + ((long long)dr * p.N + j * 32) * 4 + lane_w) = acc[i][j][r];
+          }
+        }
+    } else {
+      char *C = reinterpret_cast<char *>(p.C + bo * p.sc_o + bi * p.sc_i + (long long)row_w * p.ldc + col_w);
+      const char *R =
+          reinterpret_cast<const char *>(p.residual ? p.residual + (long long)row_w * p.ldr + col_w : nullptr);
+      char *X = reinterpret_cast<char *>(p.aux ? p.aux + (long long)row_w * p.ldaux + col_w : nullptr);
+      const unsigned lane_c = (unsigned)((4 * lh * p.ldc + li) * 4);
+      const unsigned lane_r = (unsigned)((4 * lh * p.ldr + li) * 4);
+      const unsigned lane_x = (unsigned)((4 * lh * p.ldaux + li) * 4);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = col_w + j * 32 + li;
+          const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+            const int row = row_w + dr + 4 * lh;
+            if (row < p.M && col < p.N) {
+              float v = p.alpha * acc[i][j][r];
+              float *xp = reinterpret_cast<float *>(X + ((long long)dr * p.ldaux + j * 32) * 4 + lane_x);
+              if (p.act == VITK_ACT_GELU_BWD) v *= vitk::gelu_grad(*xp);
+              v += bv;
+              if (p.act == VITK_ACT_GELU_FWD) {
+                if (p.aux != nullptr) *xp = v;
+                v = vitk::gelu_fwd(v);
+              }
+              if (p.residual != nullptr)
+                v += *reinterpret_cast<const float *>(R + ((long long)dr * p.ldr + j * 32) * 4 + lane_r);
+              *reinterpret_cast<float *>(C + ((long long)dr * p.ldc + j * 32) * 4 + lane_c) = v;
+            }
+          }
+          asm volatile("" ::: "memory");
+        }
+    }
+  }
+  VITK_STAMP(3)
+  VITK_STAMP_END()
 }
 
 // C[b][m][n] = sum_s ws[b*S + s][m][n], s ascending (fixed order => reproducible).
@@ -345,6 +533,10 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int S, int M,
     C[bo * sc_o + bi * sc_i + (long long)m * ldc + n] = s;
   }
 }
+
+#ifdef VITK_GEMM_STAMPS
+unsigned long long *g_stamps = nullptr;
+#endif
 
 struct Plan {
   int tile, tiles_m, tiles_n, batch, split_k, k_chunk;
@@ -483,13 +675,22 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   p.vec_a = strides_vec_ok(a->A, a->lda, a->stride_a_outer, a->stride_a_inner);
   p.vec_b = strides_vec_ok(a->B, a->ldb, a->stride_b_outer, a->stride_b_inner);
+#ifdef VITK_GEMM_STAMPS
+  p.stamps = g_stamps;
+  p.skip_store = getenv("VITK_GEMM_SKIP") ? atoi(getenv("VITK_GEMM_SKIP")) : 0;
+#endif
 
   hipStream_t st = vitk::as_stream(stream);
   dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)(pl.batch * pl.split_k), 1);
   // every K chunk starts and ends on a slab boundary when K and the chunk are multiples of BK
   const bool full = p.vec_a && p.vec_b && a->M % pl.tile == 0 && a->N % pl.tile == 0 && a->K > 0 &&
                     a->K % BK == 0 && pl.k_chunk % BK == 0 && a->lda < (1 << 21) && a->ldb < (1 << 21) &&
-                    a->ldc < (1 << 21) && a->ldr < (1 << 21) && a->ldaux < (1 << 21);
+                    a->ldc < (1 << 21) && a->ldr < (1 << 21) && a->ldaux < (1 << 21) &&
+                    strides_vec_ok(a->C, a->ldc, a->stride_c_outer, a->stride_c_inner) &&
+                    (a->residual == nullptr || strides_vec_ok(a->residual, a->ldr, 0, 0)) &&
+                    (a->aux == nullptr || strides_vec_ok(a->aux, a->ldaux, 0, 0)) &&
+                    (a->bias == nullptr || vitk::aligned16(a->bias)) &&
+                    (pl.split_k == 1 || vitk::aligned16(a->workspace));
   ProfRec rec{};
   if (g_prof_on) {
     rec.variant = variant_of(pl.tile, a->trans_a != 0, a->trans_b != 0, full);
@@ -513,6 +714,11 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   }
   return 0;
 }
+
+#ifdef VITK_GEMM_STAMPS
+// Diagnostic build only: device buffer of 8 x uint64 per workgroup of the next launches (or null).
+extern "C" void vitk_gemm_set_stamps(unsigned long long *device_buffer) { g_stamps = device_buffer; }
+#endif
 
 extern "C" int vitk_gemm_profile_enable(int on) {
   g_prof_on = on != 0;
