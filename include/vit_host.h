@@ -35,6 +35,11 @@ int vith_set_stream(void *hip_stream);
 int vith_synchronize(void);
 /* seeds weight initialisation, data subsampling and dropout (the reference uses random_device) */
 int vith_seed(uint64_t seed);
+/* Attention path of layers / models created AFTERWARDS: 1 (default) = the fused kernels
+ * (vitk_sdpa_fwd / vitk_sdpa_bwd) where the shape is supported, 0 = batched contractions + row
+ * softmax with the probabilities materialised (the reference's own sequence of operations,
+ * src/layers/MultiHeadAttention.cpp:96-156). */
+int vith_set_fused_attention(int on);
 uint64_t vith_device_bytes_in_use(void);
 
 /* ---- model: VisionTransformer (src/model/VisionTransformer.cpp of the reference) ------------ */

@@ -170,6 +170,27 @@ enum { VITK_DK_REFERENCE = 0, VITK_DK_EXACT = 1 };
 int vitk_dk_reference_scatter(const float *t, int32_t B, int32_t heads, int32_t N, int32_t dh, float *dk,
                               int64_t ld_dk, vitk_stream_t stream);
 
+/* ---- fused multi-head scaled-dot-product attention ---------------------------------------------
+ * One launch for  scores = Q K^T * scale -> softmax over keys -> P V  per (batch, head)
+ * (src/layers/MultiHeadAttention.cpp:96-156; cuda_Vit scaledDotProductAttention_cuda,
+ * cuda_Vit/include/utils/CudaUtils.cuh:24), and its backward (src/layers/MultiHeadAttention.cpp:
+ * 160-308) without materialising the [B*H][N][N] matrices.  q, k, v (and dq, dk, dv) address
+ * element (b, n, head, d) at ptr[(b*N + n)*ld + head*dh + d], i.e. head split / merge is address
+ * arithmetic on the packed projections; out / dout likewise with ld_out.
+ * stats (optional in the forward, required by the backward) is [B*H][N][2] = {row maximum of the
+ * scaled scores, row sum of exp(score - maximum)}: the backward recomputes the probabilities from
+ * it.  dk_mode selects the key-gradient layout (VITK_DK_*).  Supported: N <= 256, dh <= 64
+ * (vitk_sdpa_supported); callers fall back to vitk_gemm_f32 + vitk_softmax_rows otherwise.
+ * workspace: vitk_sdpa_bwd_workspace_bytes(B, H, N) bytes. */
+int vitk_sdpa_supported(int32_t N, int32_t dh);
+int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv, int32_t B, int32_t H, int32_t N,
+                  int32_t dh, float scale, float *out, int64_t ld_out, float *stats, vitk_stream_t stream);
+size_t vitk_sdpa_bwd_workspace_bytes(int32_t B, int32_t H, int32_t N);
+int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv, const float *out, const float *dout,
+                  int64_t ld_out, const float *stats, int32_t B, int32_t H, int32_t N, int32_t dh, float scale,
+                  int32_t dk_mode, float *dq, float *dk, float *dv, int64_t ld_dqkv, float *workspace,
+                  size_t workspace_bytes, vitk_stream_t stream);
+
 /* ---- patch extraction (src/layers/PatchEmbedding.cpp:31-52) -----------------------------------
  * img is [B][C][HW][HW]; patches is [B*Np][P*P*C], Np = (HW/P)^2.
  * VITK_PATCH_REFERENCE: what the reference CPU path does -- patch (ph,pw) is the P*P*C CONTIGUOUS

@@ -40,11 +40,11 @@ def empty(*shape):
     return torch.empty(shape, dtype=torch.float32, device="cuda")
 
 
-def close(got, want, tol):
+def close(got, want, tol, floor=None):
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, (got.shape, want.shape)
     assert np.isfinite(got).all()
-    e = V.max_relerr(got, want)
+    e = V.max_relerr(got, want, floor)
     assert e <= tol, f"max rel err {e:.3e} > {tol:.1e}"
 
 
@@ -422,8 +422,79 @@ def test_dk_reference_scatter(K):
     np.testing.assert_array_equal(host(out)[:, :h * dh], want)
 
 
+# ---------------------------------------- fused attention (vitk_sdpa_fwd / vitk_sdpa_bwd)
+def sdpa_numpy(q, k, v, do, scale):
+    """float64 attention per (batch, head): q, k, v, do are [B][H][N][dh]."""
+    s = np.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    m = s.max(-1, keepdims=True)
+    e = np.exp(s - m)
+    l = e.sum(-1, keepdims=True)
+    p = e / l
+    o = np.einsum("bhqk,bhkd->bhqd", p, v)
+    dp = np.einsum("bhqd,bhkd->bhqk", do, v)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) * scale
+    dq = np.einsum("bhqk,bhkd->bhqd", ds, k)
+    dk = np.einsum("bhqk,bhqd->bhkd", ds, q)
+    dv = np.einsum("bhqk,bhqd->bhkd", p, do)
+    return o, m[..., 0], l[..., 0], dq, dk, dv
+
+
+def heads_of(x, B, N, H, dh, col0):
+    """[B*N][ld] packed rows -> [B][H][N][dh] starting at column col0."""
+    return x[:, col0:col0 + H * dh].reshape(B, N, H, dh).transpose(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,H,N,dh,pad", [(2, 3, 197, 64, 0), (3, 8, 5, 12, 0), (2, 6, 17, 32, 0), (1, 2, 256, 64, 0),
+                                          (2, 2, 33, 20, 1), (1, 1, 1, 4, 0), (2, 4, 50, 16, 0), (1, 3, 129, 48, 3),
+                                          (2, 2, 64, 7, 0)])
+@pytest.mark.parametrize("dk_mode", ["reference", "exact"])
+def test_sdpa_fused_matches_float64(K, B, H, N, dh, pad, dk_mode):
+    D, M = H * dh, B * N
+    ld, ldo = 3 * D + pad, D + pad  # pad != 0: pitches that rule out 16-byte accesses
+    qkv = np.zeros((M, ld), np.float32)
+    qkv[:, :3 * D] = V.rng_normal(11, M, 3 * D)
+    do = np.zeros((M, ldo), np.float32)
+    do[:, :D] = V.rng_normal(12, M, D)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(dh)))
+    q64, k64, v64 = (heads_of(qkv.astype(np.float64), B, N, H, dh, i * D) for i in range(3))
+    o, m, l, dq, dk, dv = sdpa_numpy(q64, k64, v64, heads_of(do.astype(np.float64), B, N, H, dh, 0), scale)
+
+    assert K.dll().vitk_sdpa_supported(N, dh) == 1
+    dqkv_t = dev(qkv)
+    out, stats = torch.zeros(M, ldo, device="cuda"), empty(B * H, N, 2)
+    K.call("vitk_sdpa_fwd", dqkv_t, dqkv_t[:, D:], dqkv_t[:, 2 * D:], ld, B, H, N, dh, scale, out, ldo, stats, K.stream())
+    got_o = host(out)
+    close(heads_of(got_o, B, N, H, dh, 0), o, 1e-5)
+    assert not got_o[:, D:].any()  # nothing written past the head columns
+    st = host(stats)
+    close(st[..., 0].reshape(B, H, N), m, 1e-5, floor=1.0)  # scores are O(1) sums of dh products
+    close(st[..., 1].reshape(B, H, N), l, 1e-5)
+
+    mode = K.DK_REFERENCE if dk_mode == "reference" else K.DK_EXACT
+    nb = K.dll().vitk_sdpa_bwd_workspace_bytes(B, H, N)
+    ws, grads = empty(nb // 4), torch.zeros(M, ld, device="cuda")
+    K.call("vitk_sdpa_bwd", dqkv_t, dqkv_t[:, D:], dqkv_t[:, 2 * D:], ld, out, dev(do), ldo, stats, B, H, N, dh, scale,
+           mode, grads, grads[:, D:], grads[:, 2 * D:], ld, ws, nb, K.stream())
+    g = host(grads)
+    close(heads_of(g, B, N, H, dh, 0), dq, 1e-5)
+    close(heads_of(g, B, N, H, dh, 2 * D), dv, 1e-5)
+    if dk_mode == "exact":
+        want_dk = dk
+    else:  # the reference's [dh][N] buffer re-read as [N][dh] (src/layers/MultiHeadAttention.cpp:207-222)
+        want_dk = dk.transpose(0, 1, 3, 2).reshape(B, H, N, dh)
+    close(heads_of(g, B, N, H, dh, D), want_dk, 1e-5)
+    assert not g[:, 3 * D:].any()
+
+
+def test_sdpa_rejects_unsupported_shapes(K):
+    assert K.dll().vitk_sdpa_supported(257, 64) == 0 and K.dll().vitk_sdpa_supported(197, 65) == 0
+    x = empty(4, 4)
+    with pytest.raises(K.VitkError):
+        K.call("vitk_sdpa_fwd", x, x, x, 4, 1, 1, 300, 4, 1.0, x, 4, None, K.stream())
+
+
 # ---------------------------------------- attention block composed from the C-ABI calls
-def mha_via_abi(K, c, dk_mode):
+def mha_via_abi(K, c, dk_mode, fused=False):
     """q/k/v projection (packed [D][3D] weights), scores, softmax, PV, output projection and the
     whole backward, exactly as the host layer sequences the kernels."""
     D, h, B, N = c["D"], c["h"], c["B"], c["N"]
@@ -443,12 +514,16 @@ def mha_via_abi(K, c, dk_mode):
     scale = float(np.float32(1.0) / np.sqrt(np.float32(dh)))
     hs = dict(batch_outer=B, batch_inner=h)
     tok = (N * 3 * D, dh)
-    K.gemm(qkv, qkv[:, D:], S, N, N, dh, trans_b=True, lda=3 * D, ldb=3 * D, ldc=ld, alpha=scale, stride_a=tok,
-           stride_b=tok, stride_c=(h * N * ld, N * ld), **hs)
-    K.call("vitk_softmax_rows", S, BH * N, N, ld, S, K.stream())
     ctx = empty(M, D)
-    K.gemm(S, qkv[:, 2 * D:], ctx, N, dh, N, lda=ld, ldb=3 * D, ldc=D, stride_a=(h * N * ld, N * ld), stride_b=tok,
-           stride_c=(N * D, dh), **hs)
+    if fused:
+        stats = empty(BH, N, 2)
+        K.call("vitk_sdpa_fwd", qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B, h, N, dh, scale, ctx, D, stats, K.stream())
+    else:
+        K.gemm(qkv, qkv[:, D:], S, N, N, dh, trans_b=True, lda=3 * D, ldb=3 * D, ldc=ld, alpha=scale, stride_a=tok,
+               stride_b=tok, stride_c=(h * N * ld, N * ld), **hs)
+        K.call("vitk_softmax_rows", S, BH * N, N, ld, S, K.stream())
+        K.gemm(S, qkv[:, 2 * D:], ctx, N, dh, N, lda=ld, ldb=3 * D, ldc=D, stride_a=(h * N * ld, N * ld),
+               stride_b=tok, stride_c=(N * D, dh), **hs)
     y = empty(M, D)
     K.gemm(ctx, dev(Wo), y, M, D, D, bias=dev(bo))
     # backward
@@ -457,6 +532,11 @@ def mha_via_abi(K, c, dk_mode):
     K.gemm(dy, dev(Wo), dctx, M, D, D, trans_b=True)
     dqkv = torch.zeros(M, 3 * D, device="cuda")
     dP = torch.zeros(BH, N, ld, device="cuda")
+    if fused:
+        nb = K.dll().vitk_sdpa_bwd_workspace_bytes(B, h, N)
+        K.call("vitk_sdpa_bwd", qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, ctx, dctx, D, stats, B, h, N, dh, scale, dk_mode,
+               dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, empty(nb // 4), nb, K.stream())
+        return mha_tail(K, c, x, dy, dqkv, Wqkv, dWo, y)
     K.gemm(dctx, qkv[:, 2 * D:], dP, N, N, dh, trans_b=True, lda=D, ldb=3 * D, ldc=ld, stride_a=(N * D, dh),
            stride_b=tok, stride_c=(h * N * ld, N * ld), **hs)
     K.gemm(S, dctx, dqkv[:, 2 * D:], N, dh, N, trans_a=True, lda=ld, ldb=D, ldc=3 * D, stride_a=(h * N * ld, N * ld),
@@ -472,6 +552,13 @@ def mha_via_abi(K, c, dk_mode):
         K.gemm(qkv, dP, T, dh, N, N, trans_a=True, lda=3 * D, ldb=ld, ldc=N, stride_a=tok,
                stride_b=(h * N * ld, N * ld), stride_c=(h * dh * N, dh * N), **hs)  # Q^T dS
         K.call("vitk_dk_reference_scatter", T, B, h, N, dh, dqkv[:, D:], 3 * D, K.stream())
+    return mha_tail(K, c, x, dy, dqkv, Wqkv, dWo, y)
+
+
+def mha_tail(K, c, x, dy, dqkv, Wqkv, dWo, y):
+    """Packed projection backward shared by the fused and the unfused attention paths."""
+    D, B, N = c["D"], c["B"], c["N"]
+    M = B * N
     dWqkv, dx = empty(D, 3 * D), empty(M, D)
     K.gemm(x, dqkv, dWqkv, D, 3 * D, M, trans_a=True, split_k=0)
     K.gemm(dqkv, Wqkv, dx, M, D, 3 * D, trans_b=True)
@@ -485,11 +572,12 @@ def mha_via_abi(K, c, dk_mode):
     return host(y).reshape(B, N, D), grads, host(dx).reshape(B, N, D)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("tag", ["mha_a", "mha_b"])
-def test_attention_block_matches_reference_golden(K, tag):
+def test_attention_block_matches_reference_golden(K, tag, fused):
     g = V.golden("ops.npz")
     c = V.op_case(tag)
-    y, grads, dx = mha_via_abi(K, c, K.DK_REFERENCE)
+    y, grads, dx = mha_via_abi(K, c, K.DK_REFERENCE, fused)
     close(y, g[f"{tag}_y"], 2e-5)
     close(dx, g[f"{tag}_dx"], 2e-5)
     D = c["D"]

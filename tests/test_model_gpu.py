@@ -125,13 +125,18 @@ def test_layers_match_reference_golden(H):
 
 
 # ------------------------------------------------------------- whole model vs golden cases
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_attention", "unfused_attention"])
 @pytest.mark.parametrize("name", list(V.MODEL_CASES))
-def test_model_activations_gradients_and_steps_match_reference(H, name):
+def test_model_activations_gradients_and_steps_match_reference(H, name, fused):
     cfgd, B, seed, steps, full = V.MODEL_CASES[name]
     c = V.model_case_inputs(cfgd, B, seed, steps)
     g = V.golden(f"model_{name}.npz")
     cfg = hcfg(H, cfgd)
-    m = H.Model(cfg)
+    H.set_fused_attention(fused)  # applies to models built from here on
+    try:
+        m = H.Model(cfg)
+    finally:
+        H.set_fused_attention(True)
     shapes = V.param_shapes(c["cfg"])
     assert m.param_shapes() == [tuple(s) for s in shapes]
     m.set_params(c["prm"])

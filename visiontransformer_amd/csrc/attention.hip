@@ -1,0 +1,585 @@
+// Fused multi-head scaled-dot-product attention on the CDNA4 fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32): forward, and the backward as two kernels (query side, key side).
+// Replaces the chain   scores = Q K^T * scale -> softmax -> P V   and its backward
+// (reference: src/layers/MultiHeadAttention.cpp:96-156 forward, :160-308 backward) without ever
+// writing the [B*h][N][N] score / probability / gradient matrices to memory: the forward keeps
+// one row block of probabilities in accumulator registers and saves only the row maximum and row
+// sum; the backward recomputes probabilities from those.
+//
+// Work split: one wave owns 32 rows (queries in the forward and the query-side backward, keys in
+// the key-side backward) of one head; a workgroup is 4 such waves of the same head, which share
+// the tiles of the other side streamed through a two-stage LDS ring.
+//
+// Register-level layout (lane l = li + 32*lh, li = l&31, lh = l>>5):
+//   * a 32x32 accumulator tile D = A B holds D[(r&3) + 8*(r>>2) + 4*lh][li] in register r;
+//   * an MFMA k-step contracts two indices, one supplied by lanes lh=0 and one by lanes lh=1:
+//     operand A gives A[li][k(lh)], operand B gives B[k(lh)][li].  Contractions over the head
+//     dimension pair d = (DHP/2)*lh + j, so a lane's operand fragment is one contiguous half row;
+//   * an accumulator tile whose ROW index is the next contraction index can be fed straight back
+//     as operand B, register by register (register r pairs rows (r&3)+8*(r>>2) and that +4).
+//     Scores are therefore accumulated transposed ([key][query]) where the next product contracts
+//     over keys (P V, dS K) and plain ([query][key]) where it contracts over queries (P^T dO,
+//     dS^T Q): probabilities never leave registers.
+#include "common.h"
+
+#include <initializer_list>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int PT = 33;  // row pitch of a transposed tile [d][32 rows]: conflict-free transposing stores
+
+struct SdpaParams {
+  const float *q, *k, *v;  // element (b, n, h, d) at ptr[(b*N + n)*ld + h*dh + d]
+  long long ld;
+  float *out;              // forward output, same addressing with ldo
+  const float *o, *dout;   // backward: forward output and its gradient (ldo)
+  long long ldo;
+  float *stats;            // [B*H][N][2]: row max of the scaled scores, row sum of exp
+  float *dsum;             // [B*H][N]: sum_d dO*O (written by the query-side kernel)
+  float *dq, *dk, *dv;     // gradients, addressing as q/k/v with ldg
+  long long ldg;
+  int B, H, N, dh;
+  float scale;
+  int dk_mode;
+  int vec;                 // all pointers 16-byte aligned, all pitches and dh multiples of 4
+};
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// Cooperative 32-row x DHP tile of a [N][ld] matrix (head columns), zero-filled outside
+// (rows >= N, columns >= dh).  Thread t holds PER consecutive columns of row t/8.
+template <int DHP>
+struct Tile {
+  static constexpr int PER = DHP / 8;
+  static constexpr int PW = DHP >= 32 ? DHP : 32;  // pitch of a plain tile [32 rows][d]
+  static constexpr int PLAIN = 32 * PW, TRANS = DHP * PT;
+  __device__ static void load(const float *__restrict__ base, long long ld, int row0, int N, int dh, bool vec,
+                              float (&r)[PER]) {
+    const int row = row0 + (threadIdx.x >> 3), c0 = (threadIdx.x & 7) * PER;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) r[e] = 0.f;
+    if (row >= N) return;
+    const float *p = base + (long long)row * ld + c0;
+    if constexpr (PER >= 4) {
+      if (vec) {
+#pragma unroll
+        for (int v = 0; v < PER / 4; ++v)
+          if (c0 + 4 * v < dh) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * v);
+            r[4 * v] = t.x; r[4 * v + 1] = t.y; r[4 * v + 2] = t.z; r[4 * v + 3] = t.w;
+          }
+        return;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+      if (c0 + e < dh) r[e] = p[e];
+  }
+  __device__ static void store_plain(float *__restrict__ dst, const float (&r)[PER]) {
+    float *d = dst + (threadIdx.x >> 3) * PW + (threadIdx.x & 7) * PER;
+    if constexpr (PER >= 4) {
+#pragma unroll
+      for (int v = 0; v < PER / 4; ++v) {
+        const f32x4 t = {r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]};
+        *reinterpret_cast<f32x4 *>(d + 4 * v) = t;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PER; ++e) d[e] = r[e];
+    }
+  }
+  __device__ static void store_trans(float *__restrict__ dst, const float (&r)[PER]) {
+    float *d = dst + ((threadIdx.x & 7) * PER) * PT + (threadIdx.x >> 3);
+#pragma unroll
+    for (int e = 0; e < PER; ++e) d[e * PT] = r[e];
+  }
+};
+
+// One lane's operand fragment of its own row: X[row][(DHP/2)*lh + j], j < DHP/2 (zero outside).
+template <int DHP>
+__device__ __forceinline__ void load_fragment(const float *__restrict__ base, long long ld, int row, int N, int dh,
+                                              bool vec, int lh, float (&f)[DHP / 2]) {
+  constexpr int HALF = DHP / 2;
+#pragma unroll
+  for (int j = 0; j < HALF; ++j) f[j] = 0.f;
+  if (row >= N) return;
+  const float *p = base + (long long)row * ld + HALF * lh;
+  if constexpr (HALF % 4 == 0) {
+    if (vec) {
+#pragma unroll
+      for (int v = 0; v < HALF / 4; ++v)
+        if (HALF * lh + 4 * v < dh) {
+          const f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * v);
+          f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
+        }
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < HALF; ++j)
+    if (HALF * lh + j < dh) f[j] = p[j];
+}
+
+// Store a transposed result tile set acc[t][4g+e] = X^T[d = 32t + 8g + 4lh + e][row li] as row `row`.
+template <int DT>
+__device__ __forceinline__ void store_rows(float *__restrict__ rowp, const f32x16 (&acc)[DT], int dh, bool vec,
+                                           int lh) {
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = 32 * t + 8 * g + 4 * lh;
+      if (vec) {
+        if (d0 < dh) {
+          const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+          *reinterpret_cast<f32x4 *>(rowp + d0) = v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (d0 + e < dh) rowp[d0 + e] = acc[t][4 * g + e];
+      }
+    }
+}
+
+#define VITK_ROW_OF(r) (((r)&3) + 8 * ((r) >> 2))
+
+// ---- forward --------------------------------------------------------------------------------------
+// Pass 1 streams the key tiles and accumulates the whole score row block S^T[key][query] of the
+// wave (NKT tiles x 16 registers); softmax runs on registers (a row lives in one lane pair);
+// pass 2 streams the value tiles and accumulates O^T[d][query] with the probabilities as operand B.
+template <int DHP, int NKT>
+__global__ __launch_bounds__(THREADS, 2) void sdpa_fwd_kernel(const SdpaParams p) {
+  using T = Tile<DHP>;
+  constexpr int HALF = DHP / 2, DT = DHP >= 32 ? DHP / 32 : 1, PW = T::PW;
+  constexpr int STAGE = T::TRANS > T::PLAIN ? T::TRANS : T::PLAIN;
+  __shared__ __attribute__((aligned(16))) float ring[2 * STAGE];
+  const int nqb = (p.N + 127) / 128;
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+  const int b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int q0 = qb * 128 + wave * 32;
+  const bool active = q0 < p.N;  // wave-uniform; idle waves still help to stage tiles
+  const int nkt = (p.N + 31) / 32;
+  const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
+  const float *Q = p.q + head, *K = p.k + head, *V = p.v + head;
+  const bool vec = p.vec != 0;
+  if constexpr (DHP < 32) {  // padding columns of the plain tiles stay zero
+    for (int i = threadIdx.x; i < 2 * STAGE; i += THREADS) ring[i] = 0.f;
+    __syncthreads();
+  }
+
+  float qf[HALF];
+  load_fragment<DHP>(Q, p.ld, q0 + li, p.N, p.dh, vec, lh, qf);
+
+  f32x16 s[NKT];
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) s[j] = zero16();
+  float lr[T::PER];
+  T::load(K, p.ld, 0, p.N, p.dh, vec, lr);
+  T::store_trans(ring, lr);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    if (j < nkt) {
+      if (j + 1 < nkt) T::load(K, p.ld, 32 * (j + 1), p.N, p.dh, vec, lr);
+      else T::load(V, p.ld, 0, p.N, p.dh, vec, lr);
+      if (active) {
+        const float *ks = ring + (j & 1) * STAGE + (HALF * lh) * PT + li;
+#pragma unroll
+        for (int jj = 0; jj < HALF; ++jj)
+          s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[jj * PT], qf[jj], s[j], 0, 0, 0);
+      }
+      float *nxt = ring + ((j + 1) & 1) * STAGE;
+      if (j + 1 < nkt) T::store_trans(nxt, lr);
+      else T::store_plain(nxt, lr);
+      __syncthreads();
+    }
+  }
+
+  if (active) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * j + VITK_ROW_OF(r) + 4 * lh;
+        const float x = key < p.N ? s[j][r] * p.scale : -INFINITY;
+        s[j][r] = x;
+        m = fmaxf(m, x);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(s[j][r] - m);
+        s[j][r] = e;
+        l += e;
+      }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[j][r] *= inv;
+    if (p.stats != nullptr && lh == 0 && q0 + li < p.N) {
+      float *st = p.stats + ((long long)bh * p.N + q0 + li) * 2;
+      st[0] = m;
+      st[1] = l;
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) o[t] = zero16();
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    if (j < nkt) {
+      if (j + 1 < nkt) T::load(V, p.ld, 32 * (j + 1), p.N, p.dh, vec, lr);
+      if (active) {
+        const float *vs = ring + ((nkt + j) & 1) * STAGE + (4 * lh) * PW + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[VITK_ROW_OF(r) * PW + 32 * t], s[j][r], o[t], 0, 0, 0);
+      }
+      if (j + 1 < nkt) T::store_plain(ring + ((nkt + j + 1) & 1) * STAGE, lr);
+      __syncthreads();
+    }
+  }
+  if (active && q0 + li < p.N)
+    store_rows<DT>(p.out + ((long long)b * p.N + q0 + li) * p.ldo + (long long)h * p.dh, o, p.dh, vec, lh);
+}
+
+// ---- backward, query side: dQ (and dsum = rowsum(dO*O) for the key side) --------------------------
+// Per key tile: S^T = K Q^T and dP^T = V dO^T (both [key][query]), P from the saved row statistics,
+// dS^T = P^T (dP^T - dsum) * scale, dQ^T[d][query] += K^T dS^T with dS^T as operand B.
+template <int DHP>
+__global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dq_kernel(const SdpaParams p) {
+  using T = Tile<DHP>;
+  constexpr int HALF = DHP / 2, DT = DHP >= 32 ? DHP / 32 : 1, PW = T::PW;
+  constexpr int STAGE = 2 * T::TRANS + T::PLAIN;  // K^T, V^T, K
+  __shared__ __attribute__((aligned(16))) float ring[2 * STAGE];
+  const int nqb = (p.N + 127) / 128;
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+  const int b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int q0 = qb * 128 + wave * 32, q = q0 + li;
+  const bool active = q0 < p.N;
+  const int nkt = (p.N + 31) / 32;
+  const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
+  const long long ohead = (long long)b * p.N * p.ldo + (long long)h * p.dh;
+  const float *Q = p.q + head, *K = p.k + head, *V = p.v + head;
+  const bool vec = p.vec != 0;
+  if constexpr (DHP < 32) {
+    for (int i = threadIdx.x; i < 2 * STAGE; i += THREADS) ring[i] = 0.f;
+    __syncthreads();
+  }
+
+  float qf[HALF], dof[HALF];
+  load_fragment<DHP>(Q, p.ld, q, p.N, p.dh, vec, lh, qf);
+  load_fragment<DHP>(p.dout + ohead, p.ldo, q, p.N, p.dh, vec, lh, dof);
+  float dsum = 0.f, m = 0.f, inv = 0.f;
+  if (active) {
+    float of[HALF];
+    load_fragment<DHP>(p.o + ohead, p.ldo, q, p.N, p.dh, vec, lh, of);
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) dsum += dof[j] * of[j];
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (q < p.N) {
+      const float *st = p.stats + ((long long)bh * p.N + q) * 2;
+      m = st[0];
+      inv = 1.0f / st[1];
+      if (lh == 0) p.dsum[(long long)bh * p.N + q] = dsum;
+    }
+  }
+
+  f32x16 dq[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) dq[t] = zero16();
+  float kr[T::PER], vr[T::PER];
+  T::load(K, p.ld, 0, p.N, p.dh, vec, kr);
+  T::load(V, p.ld, 0, p.N, p.dh, vec, vr);
+  T::store_trans(ring, kr);
+  T::store_trans(ring + T::TRANS, vr);
+  T::store_plain(ring + 2 * T::TRANS, kr);
+  __syncthreads();
+  for (int j = 0; j < nkt; ++j) {
+    if (j + 1 < nkt) {
+      T::load(K, p.ld, 32 * (j + 1), p.N, p.dh, vec, kr);
+      T::load(V, p.ld, 32 * (j + 1), p.N, p.dh, vec, vr);
+    }
+    if (active) {
+      const float *st = ring + (j & 1) * STAGE;
+      const float *kt = st + (HALF * lh) * PT + li, *vt = kt + T::TRANS;
+      const float *kp = st + 2 * T::TRANS + (4 * lh) * PW + li;
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int jj = 0; jj < HALF; ++jj) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[jj * PT], qf[jj], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[jj * PT], dof[jj], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * j + VITK_ROW_OF(r) + 4 * lh;
+        const float pr = key < p.N ? __expf(s[r] * p.scale - m) * inv : 0.f;
+        s[r] = (pr * (dp[r] - dsum)) * p.scale;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[VITK_ROW_OF(r) * PW + 32 * t], s[r], dq[t], 0, 0, 0);
+    }
+    if (j + 1 < nkt) {
+      float *nx = ring + ((j + 1) & 1) * STAGE;
+      T::store_trans(nx, kr);
+      T::store_trans(nx + T::TRANS, vr);
+      T::store_plain(nx + 2 * T::TRANS, kr);
+    }
+    __syncthreads();
+  }
+  if (active && q < p.N)
+    store_rows<DT>(p.dq + ((long long)b * p.N + q) * p.ldg + (long long)h * p.dh, dq, p.dh, vec, lh);
+}
+
+template <int DHP>
+struct DkvStage {
+  static constexpr int value = 2 * Tile<DHP>::TRANS + 2 * Tile<DHP>::PLAIN + 96;
+};
+
+// ---- backward, key side: dK and dV ----------------------------------------------------------------
+// Per query tile: S = Q K^T and dP = dO V^T (both [query][key]), P, dS as above (row statistics
+// come from LDS: the query index is the register index here), then
+// dV^T[d][key] += dO^T P and dK^T[d][key] += Q^T dS with P / dS as operand B.
+template <int DHP>
+__global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaParams p) {
+  using T = Tile<DHP>;
+  constexpr int HALF = DHP / 2, DT = DHP >= 32 ? DHP / 32 : 1, PW = T::PW;
+  constexpr int STAGE = DkvStage<DHP>::value;  // Q^T, dO^T, Q, dO, {max, 1/sum, dsum}[32]
+  extern __shared__ __attribute__((aligned(16))) float ring[];  // 2 * STAGE floats (above 64 KB for dh = 64)
+  const int nkb = (p.N + 127) / 128;
+  const int bh = blockIdx.x / nkb, kb = blockIdx.x % nkb;
+  const int b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int k0 = kb * 128 + wave * 32, key = k0 + li;
+  const bool active = k0 < p.N;
+  const int nqt = (p.N + 31) / 32;
+  const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
+  const long long ohead = (long long)b * p.N * p.ldo + (long long)h * p.dh;
+  const float *Q = p.q + head, *K = p.k + head, *V = p.v + head, *DO = p.dout + ohead;
+  const bool vec = p.vec != 0;
+  if constexpr (DHP < 32) {
+    for (int i = threadIdx.x; i < 2 * STAGE; i += THREADS) ring[i] = 0.f;
+    __syncthreads();
+  }
+
+  float kf[HALF], vf[HALF];
+  load_fragment<DHP>(K, p.ld, key, p.N, p.dh, vec, lh, kf);
+  load_fragment<DHP>(V, p.ld, key, p.N, p.dh, vec, lh, vf);
+  const bool key_ok = key < p.N;
+
+  f32x16 dk[DT], dv[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) dk[t] = zero16(), dv[t] = zero16();
+  float qr[T::PER], gr[T::PER], sm = 0.f, si = 0.f, sd = 0.f;
+  // row statistics of a query tile: threads 0..31 fetch {max, 1/sum, dsum} of query 32*i + t
+#define VITK_LOAD_STATS(I)                                                    \
+  if (threadIdx.x < 32) {                                                     \
+    const int qq = 32 * (I) + threadIdx.x;                                    \
+    sm = 0.f, si = 0.f, sd = 0.f;                                             \
+    if (qq < p.N) {                                                           \
+      const float *st = p.stats + ((long long)bh * p.N + qq) * 2;             \
+      sm = st[0];                                                             \
+      si = 1.0f / st[1];                                                      \
+      sd = p.dsum[(long long)bh * p.N + qq];                                  \
+    }                                                                         \
+  }
+#define VITK_STORE_STAGE(DST)                                                 \
+  {                                                                           \
+    float *nx = (DST);                                                        \
+    T::store_trans(nx, qr);                                                   \
+    T::store_trans(nx + T::TRANS, gr);                                        \
+    T::store_plain(nx + 2 * T::TRANS, qr);                                    \
+    T::store_plain(nx + 2 * T::TRANS + T::PLAIN, gr);                         \
+    if (threadIdx.x < 32) {                                                   \
+      float *ss = nx + 2 * T::TRANS + 2 * T::PLAIN;                           \
+      ss[threadIdx.x] = sm;                                                   \
+      ss[32 + threadIdx.x] = si;                                              \
+      ss[64 + threadIdx.x] = sd;                                              \
+    }                                                                         \
+  }
+  T::load(Q, p.ld, 0, p.N, p.dh, vec, qr);
+  T::load(DO, p.ldo, 0, p.N, p.dh, vec, gr);
+  VITK_LOAD_STATS(0)
+  VITK_STORE_STAGE(ring)
+  __syncthreads();
+  for (int i = 0; i < nqt; ++i) {
+    if (i + 1 < nqt) {
+      T::load(Q, p.ld, 32 * (i + 1), p.N, p.dh, vec, qr);
+      T::load(DO, p.ldo, 32 * (i + 1), p.N, p.dh, vec, gr);
+      VITK_LOAD_STATS(i + 1)
+    }
+    if (active) {
+      const float *st = ring + (i & 1) * STAGE;
+      const float *qt = st + (HALF * lh) * PT + li, *gt = qt + T::TRANS;
+      const float *qp = st + 2 * T::TRANS + (4 * lh) * PW + li, *gp = qp + T::PLAIN;
+      const float *ss = st + 2 * T::TRANS + 2 * T::PLAIN + 4 * lh;
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int jj = 0; jj < HALF; ++jj) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qt[jj * PT], kf[jj], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[jj * PT], vf[jj], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ss + 8 * g);
+        const f32x4 i4 = *reinterpret_cast<const f32x4 *>(ss + 32 + 8 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(ss + 64 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pr = key_ok ? __expf(s[r] * p.scale - m4[e]) * i4[e] : 0.f;
+          s[r] = pr;
+          dp[r] = (pr * (dp[r] - d4[e])) * p.scale;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          dv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[VITK_ROW_OF(r) * PW + 32 * t], s[r], dv[t], 0, 0, 0);
+          dk[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[VITK_ROW_OF(r) * PW + 32 * t], dp[r], dk[t], 0, 0, 0);
+        }
+    }
+    if (i + 1 < nqt) VITK_STORE_STAGE(ring + ((i + 1) & 1) * STAGE)
+    __syncthreads();
+  }
+#undef VITK_LOAD_STATS
+#undef VITK_STORE_STAGE
+  if (!active || !key_ok) return;
+  store_rows<DT>(p.dv + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dv, p.dh, vec, lh);
+  if (p.dk_mode == VITK_DK_EXACT) {
+    store_rows<DT>(p.dk + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dk, p.dh, vec, lh);
+  } else {
+    // The reference forms Q^T dS as [dh][N] per head and re-reads that buffer as [N][dh]
+    // (src/layers/MultiHeadAttention.cpp:207-222): element (d, key) lands at flat index d*N + key.
+    float *base = p.dk + (long long)b * p.N * p.ldg + (long long)h * p.dh;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = 32 * t + VITK_ROW_OF(r) + 4 * lh;
+        if (d < p.dh) {
+          const int f = d * p.N + key;
+          base[(long long)(f / p.dh) * p.ldg + f % p.dh] = dk[t][r];
+        }
+      }
+  }
+}
+
+template <int DHP>
+int launch_fwd(const SdpaParams &p, int grid, hipStream_t st) {
+  const int nkt = (p.N + 31) / 32;
+  if (nkt <= 1) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 1>), dim3(grid), dim3(THREADS), 0, st, p);
+  else if (nkt <= 2) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 2>), dim3(grid), dim3(THREADS), 0, st, p);
+  else if (nkt <= 4) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 4>), dim3(grid), dim3(THREADS), 0, st, p);
+  else if (nkt <= 7) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 7>), dim3(grid), dim3(THREADS), 0, st, p);  // 224/16
+  else hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 8>), dim3(grid), dim3(THREADS), 0, st, p);
+  return vitk::check_launch("vitk_sdpa_fwd");
+}
+
+template <int DHP>
+int launch_bwd(const SdpaParams &p, dim3 grid, hipStream_t st) {
+  const size_t lds = 2 * DkvStage<DHP>::value * sizeof(float);
+  static bool configured = false;  // raise the dynamic LDS limit once per instantiation
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd_dkv_kernel<DHP>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    VITK_REQUIRE(e == hipSuccess, "vitk_sdpa_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((sdpa_bwd_dq_kernel<DHP>), grid, dim3(THREADS), 0, st, p);
+  hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<DHP>), grid, dim3(THREADS), lds, st, p);
+  return vitk::check_launch("vitk_sdpa_bwd");
+}
+
+bool all_vec(std::initializer_list<const void *> ptrs, std::initializer_list<long long> pitches) {
+  for (const void *q : ptrs)
+    if (q != nullptr && !vitk::aligned16(q)) return false;
+  for (long long v : pitches)
+    if (v % 4 != 0) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitk_sdpa_supported(int32_t N, int32_t dh) { return N >= 1 && N <= 256 && dh >= 1 && dh <= 64; }
+
+int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv, int32_t B, int32_t H, int32_t N,
+                  int32_t dh, float scale, float *out, int64_t ld_out, float *stats, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && H >= 1 && N >= 0 && dh >= 1, "vitk_sdpa_fwd: bad shape (B=%d H=%d N=%d dh=%d)", B, H, N, dh);
+  if (B == 0 || N == 0) return 0;
+  VITK_REQUIRE(vitk_sdpa_supported(N, dh), "vitk_sdpa_fwd: needs N <= 256 and dh <= 64 (N=%d dh=%d)", N, dh);
+  VITK_REQUIRE(q && k && v && out, "vitk_sdpa_fwd: null pointer");
+  VITK_REQUIRE(ld_qkv >= (int64_t)H * dh && ld_out >= (int64_t)H * dh, "vitk_sdpa_fwd: pitch smaller than H*dh");
+  const long long blocks = (long long)B * H * ((N + 127) / 128);
+  VITK_REQUIRE(blocks < (1ll << 31), "vitk_sdpa_fwd: too many workgroups");
+  SdpaParams p{};
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.out = out; p.ldo = ld_out; p.stats = stats;
+  p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale;
+  p.vec = all_vec({q, k, v, out}, {ld_qkv, ld_out, dh});
+  hipStream_t st = vitk::as_stream(stream);
+  if (dh <= 16) return launch_fwd<16>(p, (int)blocks, st);
+  if (dh <= 32) return launch_fwd<32>(p, (int)blocks, st);
+  return launch_fwd<64>(p, (int)blocks, st);
+}
+
+size_t vitk_sdpa_bwd_workspace_bytes(int32_t B, int32_t H, int32_t N) {
+  return (B > 0 && H > 0 && N > 0) ? (size_t)B * H * N * sizeof(float) : 0;
+}
+
+int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv, const float *out, const float *dout,
+                  int64_t ld_out, const float *stats, int32_t B, int32_t H, int32_t N, int32_t dh, float scale,
+                  int32_t dk_mode, float *dq, float *dk, float *dv, int64_t ld_dqkv, float *workspace,
+                  size_t workspace_bytes, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && H >= 1 && N >= 0 && dh >= 1, "vitk_sdpa_bwd: bad shape (B=%d H=%d N=%d dh=%d)", B, H, N, dh);
+  if (B == 0 || N == 0) return 0;
+  VITK_REQUIRE(vitk_sdpa_supported(N, dh), "vitk_sdpa_bwd: needs N <= 256 and dh <= 64 (N=%d dh=%d)", N, dh);
+  VITK_REQUIRE(q && k && v && out && dout && stats && dq && dk && dv, "vitk_sdpa_bwd: null pointer");
+  VITK_REQUIRE(dk_mode == VITK_DK_REFERENCE || dk_mode == VITK_DK_EXACT, "vitk_sdpa_bwd: unknown dk_mode %d", dk_mode);
+  VITK_REQUIRE(ld_qkv >= (int64_t)H * dh && ld_out >= (int64_t)H * dh && ld_dqkv >= (int64_t)H * dh,
+               "vitk_sdpa_bwd: pitch smaller than H*dh");
+  VITK_REQUIRE(workspace != nullptr && workspace_bytes >= vitk_sdpa_bwd_workspace_bytes(B, H, N),
+               "vitk_sdpa_bwd: needs %zu workspace bytes, got %zu", vitk_sdpa_bwd_workspace_bytes(B, H, N),
+               workspace_bytes);
+  const long long blocks = (long long)B * H * ((N + 127) / 128);
+  VITK_REQUIRE(blocks < (1ll << 31), "vitk_sdpa_bwd: too many workgroups");
+  SdpaParams p{};
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.o = out; p.dout = dout; p.ldo = ld_out;
+  p.stats = const_cast<float *>(stats); p.dsum = workspace;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.ldg = ld_dqkv;
+  p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale; p.dk_mode = dk_mode;
+  p.vec = all_vec({q, k, v, out, dout, dq, dk, dv}, {ld_qkv, ld_out, ld_dqkv, dh});
+  hipStream_t st = vitk::as_stream(stream);
+  const dim3 grid((unsigned)blocks);
+  if (dh <= 16) return launch_bwd<16>(p, grid, st);
+  if (dh <= 32) return launch_bwd<32>(p, grid, st);
+  return launch_bwd<64>(p, grid, st);
+}
+
+}  // extern "C"

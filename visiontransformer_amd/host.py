@@ -45,6 +45,7 @@ SIGNATURES = {
     "vith_set_stream": (_int, [_p]),
     "vith_synchronize": (_int, []),
     "vith_seed": (_int, [_u64]),
+    "vith_set_fused_attention": (_int, [_int]),
     "vith_device_bytes_in_use": (_u64, []),
     "vith_model_create": (_p, [C.POINTER(Config), _int, _int]),
     "vith_model_destroy": (None, [_p]),
@@ -121,6 +122,11 @@ def use_torch_stream():
     """Enqueue all host-layer work on torch's current CUDA stream."""
     import torch
     _check(dll().vith_set_stream(torch.cuda.current_stream().cuda_stream))
+
+
+def set_fused_attention(on):
+    """Attention path of models / layers created afterwards (see include/vit_host.h)."""
+    _check(dll().vith_set_fused_attention(int(bool(on))))
 
 
 def seed(s):

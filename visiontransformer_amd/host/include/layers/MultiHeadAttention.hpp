@@ -29,14 +29,20 @@ public:
   // the mathematically correct gradient.  Process-wide default for newly built layers.
   static void setDefaultKeyGradMode(int mode);
   void setKeyGradMode(int mode) { dk_mode = mode; }
+  // Fused attention kernels (default, where the shape is supported) or the chain of batched
+  // contractions + row softmax that materialises the probabilities.
+  static void setDefaultFused(bool on);
+  void setFused(bool on) { use_fused = on; }
 
 private:
   void build(vit::ParamArena &arena, bool initialise);
+  Tensor projectionBackward(const Tensor &dqkv);
   size_t embedding_dim, num_heads, head_dim;
   int dk_mode;
+  bool use_fused;
   Tensor wqkv, bqkv, dwqkv, dbqkv;       // packed {D,3D} / {1,3D}
   std::unique_ptr<Dense> q_proj, k_proj, v_proj, out_proj;
-  Tensor inputTensor, qkv, attention_weights, context;
+  Tensor inputTensor, qkv, attention_weights, softmax_stats, context;
 };
 
 #endif  // MULTIHEADATTENTION_HPP

@@ -9,16 +9,18 @@ using vit::GemmOpts;
 namespace {
 void *S() { return vit::stream(); }
 int g_default_dk_mode = VITK_DK_REFERENCE;
+bool g_default_fused = true;
 }  // namespace
 
 void MultiHeadAttention::setDefaultKeyGradMode(int mode) { g_default_dk_mode = mode; }
+void MultiHeadAttention::setDefaultFused(bool on) { g_default_fused = on; }
 
 MultiHeadAttention::MultiHeadAttention(size_t embedding_dim, size_t num_heads)
     : MultiHeadAttention(embedding_dim, num_heads,
                          *std::make_unique<vit::ParamArena>(4 * (embedding_dim * embedding_dim + embedding_dim))) {}
 
 MultiHeadAttention::MultiHeadAttention(size_t embedding_dim, size_t num_heads, vit::ParamArena &arena)
-    : embedding_dim(embedding_dim), num_heads(num_heads), dk_mode(g_default_dk_mode) {
+    : embedding_dim(embedding_dim), num_heads(num_heads), dk_mode(g_default_dk_mode), use_fused(g_default_fused) {
   if (num_heads == 0 || embedding_dim % num_heads != 0)
     throw std::invalid_argument("embedding_dim debe ser divisible por num_heads.");
   head_dim = embedding_dim / num_heads;
@@ -65,11 +67,29 @@ Tensor MultiHeadAttention::forwardFused(const Tensor &input, bool isTraining, co
   o1.bias = bqkv.deviceData();
   vit::gemm(false, false, M, 3 * D, D, x.deviceData(), D, wqkv.deviceData(), 3 * D, qkvT.deviceDataOverwrite(), 3 * D, o1);
   const float *q = qkvT.deviceData(), *k = q + D, *v = q + 2 * D;
+  const float scale = 1.0f / std::sqrt(static_cast<float>(head_dim));
+  if (use_fused && vitk_sdpa_supported((int32_t)N, (int32_t)dh)) {
+    // 2+3 in one launch: scores, softmax and P V stay in registers; only the row statistics of the
+    // softmax are kept for the backward.
+    Tensor ctx = Tensor::deviceEmpty({(size_t)B, (size_t)N, (size_t)D});
+    Tensor stats = isTraining ? Tensor::deviceEmpty({(size_t)BH, (size_t)N, 2}) : Tensor();
+    vit::check(vitk_sdpa_fwd(q, k, v, 3 * D, (int32_t)B, (int32_t)h, (int32_t)N, (int32_t)dh, scale,
+                             ctx.deviceDataOverwrite(), D, isTraining ? stats.deviceDataOverwrite() : nullptr, S()),
+               "vitk_sdpa_fwd");
+    if (isTraining) {
+      inputTensor = x;
+      qkv = qkvT;
+      attention_weights = Tensor();
+      softmax_stats = stats;
+      context = ctx;
+    }
+    return out_proj->forwardFused(ctx, isTraining, VITK_ACT_NONE, nullptr, residual);
+  }
   // 2. scores = (Q K^T) / sqrt(dh), softmax over keys (rows padded to a multiple of 4 floats)
   const int64_t ld = (N + 3) / 4 * 4;
   Tensor P = Tensor::deviceEmpty({(size_t)BH, (size_t)N, (size_t)ld});
   GemmOpts o2;
-  o2.alpha = 1.0f / std::sqrt(static_cast<float>(head_dim));
+  o2.alpha = scale;
   o2.batch_outer = (int)B; o2.batch_inner = (int)h;
   o2.sa_o = N * 3 * D; o2.sa_i = dh; o2.sb_o = N * 3 * D; o2.sb_i = dh; o2.sc_o = h * N * ld; o2.sc_i = N * ld;
   float *Pd = P.deviceDataOverwrite();
@@ -85,6 +105,7 @@ Tensor MultiHeadAttention::forwardFused(const Tensor &input, bool isTraining, co
     inputTensor = x;
     qkv = qkvT;
     attention_weights = P;
+    softmax_stats = Tensor();
     context = ctx;
   }
   // 4. output projection (+ residual of the enclosing block)
@@ -96,14 +117,23 @@ Tensor MultiHeadAttention::backward(const Tensor &outputGradient) {
   const auto &s = inputTensor.getShape();
   const int64_t B = (int64_t)s[0], N = (int64_t)s[1], D = (int64_t)embedding_dim, h = (int64_t)num_heads,
                 dh = (int64_t)head_dim, M = B * N, BH = B * h;
-  const int64_t ld = (int64_t)attention_weights.getShape()[2];
   // 1. output projection
   Tensor dctx = out_proj->backward(outputGradient);  // {B,N,D}
   const float *dc = dctx.deviceData();
   const float *q = qkv.deviceData(), *k = q + D, *v = q + 2 * D;
-  const float *P = attention_weights.deviceData();
   Tensor dqkv = Tensor::deviceEmpty({(size_t)M, (size_t)(3 * D)});
   float *dq = dqkv.deviceDataOverwrite(), *dk = dq + D, *dv = dq + 2 * D;
+  if (softmax_stats.defined()) {
+    // 2-5 fused: probabilities are recomputed from the saved row statistics
+    const size_t wsb = vitk_sdpa_bwd_workspace_bytes((int32_t)B, (int32_t)h, (int32_t)N);
+    vit::check(vitk_sdpa_bwd(q, k, v, 3 * D, context.deviceData(), dc, D, softmax_stats.deviceData(), (int32_t)B,
+                             (int32_t)h, (int32_t)N, (int32_t)dh, 1.0f / std::sqrt(static_cast<float>(head_dim)),
+                             dk_mode, dq, dk, dv, 3 * D, vit::workspace(wsb), wsb, S()),
+               "vitk_sdpa_bwd");
+    return projectionBackward(dqkv);
+  }
+  const int64_t ld = (int64_t)attention_weights.getShape()[2];
+  const float *P = attention_weights.deviceData();
   const int64_t tok = N * 3 * D, sP_o = h * N * ld, sP_i = N * ld;
   auto heads = [&](GemmOpts &o) { o.batch_outer = (int)B; o.batch_inner = (int)h; };
   // 2. dP = dctx V^T ; dV = P^T dctx
@@ -143,7 +173,14 @@ Tensor MultiHeadAttention::backward(const Tensor &outputGradient) {
     vit::check(vitk_dk_reference_scatter(T.deviceData(), (int32_t)B, (int32_t)h, (int32_t)N, (int32_t)dh, dk, 3 * D, S()),
                "vitk_dk_reference_scatter");
   }
-  // 6. packed projection backward: dW_qkv = X^T dQKV, db_qkv = colsum, dX = dQKV W_qkv^T
+  return projectionBackward(dqkv);
+}
+
+// packed projection backward: dW_qkv = X^T dQKV, db_qkv = colsum, dX = dQKV W_qkv^T
+Tensor MultiHeadAttention::projectionBackward(const Tensor &dqkv) {
+  const auto &s = inputTensor.getShape();
+  const int64_t D = (int64_t)embedding_dim, M = (int64_t)(s[0] * s[1]);
+  const float *dq = dqkv.deviceData();
   const float *x = inputTensor.deviceData();
   {
     GemmOpts o;

@@ -89,6 +89,9 @@ int vith_init(int device) { return guard([&] { vit::init(device); }); }
 int vith_set_stream(void *s) { return guard([&] { vit::set_stream(s); }); }
 int vith_synchronize(void) { return guard([&] { vit::synchronize(); }); }
 int vith_seed(uint64_t seed) { return guard([&] { vit::seed(seed); }); }
+int vith_set_fused_attention(int on) {
+  return guard([&] { MultiHeadAttention::setDefaultFused(on != 0); });
+}
 uint64_t vith_device_bytes_in_use(void) { return vit::device_bytes_in_use(); }
 
 vith_model vith_model_create(const vith_config *cfg, int patch_mode, int dk_mode) {
