@@ -50,7 +50,7 @@ struct Params {
   long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
   int split_k, k_chunk;
   float *ws;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, strip;
   int vec_a, vec_b;
 #ifdef VITK_GEMM_STAMPS
   unsigned long long *stamps;  // diagnostic build only: 8 clock stamps per workgroup
@@ -227,15 +227,22 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   VITK_STAMP(0)
   VITK_STAMP_AUX()
 
-  // XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) get a contiguous run of
-  // tiles, and consecutive tiles share the A row panel, so panel re-reads hit that XCD's L2.
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-  const int tm = swz / p.tiles_n, tn = swz % p.tiles_n;
+  // XCD-aware work order.  Workgroups are handed to the 8 XCDs round-robin by linear id, and each
+  // XCD has its own L2.  All (batch, K-split, tile) work items are laid out in one sequence in which
+  // neighbours share operand panels -- K-split major (workgroups of one split read the same rows
+  // of both operands), then column strips of `strip` tiles walked down the rows (a strip of the
+  // B operand stays hot while A panels stream past) -- and XCD x takes the x-th contiguous eighth
+  // of that sequence, so what is resident on an XCD at any time is a compact block of the problem.
+  const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = total / 8, r8 = total % 8, xcd = lin % 8;
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin / 8;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = work / tiles, tix = work % tiles;
+  const int strip_items = p.tiles_m * p.strip, sidx = tix / strip_items, rem = tix % strip_items;
+  const int strip_w = min(p.strip, p.tiles_n - sidx * p.strip);
+  const int tm = rem / strip_w, tn = sidx * p.strip + rem % strip_w;
   const int m0 = tm * TILE, n0 = tn * TILE;
 
-  const int z = blockIdx.y;
   const int batch = z / p.split_k, ks = z % p.split_k;
   const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
   const float *__restrict__ A = p.A + bo * p.sa_o + bi * p.sa_i;
@@ -673,6 +680,11 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   p.sc_o = a->stride_c_outer; p.sc_i = a->stride_c_inner;
   p.split_k = pl.split_k; p.k_chunk = pl.k_chunk; p.ws = a->workspace;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  {  // column strips of at most 8 tiles, as even as possible
+    static const int strip_env = getenv("VITK_GEMM_STRIP") ? atoi(getenv("VITK_GEMM_STRIP")) : 8;
+    const int nstrips = (pl.tiles_n + strip_env - 1) / strip_env;
+    p.strip = (pl.tiles_n + nstrips - 1) / nstrips;
+  }
   p.vec_a = strides_vec_ok(a->A, a->lda, a->stride_a_outer, a->stride_a_inner);
   p.vec_b = strides_vec_ok(a->B, a->ldb, a->stride_b_outer, a->stride_b_inner);
 #ifdef VITK_GEMM_STAMPS
