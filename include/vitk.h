@@ -84,6 +84,10 @@ typedef struct vitk_gemm_args {
   int32_t reserved;
   float *workspace;
   size_t workspace_bytes;
+  /* optional: colsum_b[n] = sum_k B[k][n] (trans_b = 0, batch = 1 only), accumulated from the B
+   * tiles the contraction loads anyway -- the bias gradient sum(0) of Dense::backward
+   * (src/layers/Dense.cpp:95) comes for free with dW = X^T dY.  Fixed summation order. */
+  float *colsum_b;
 } vitk_gemm_args;
 
 int vitk_gemm_f32(const vitk_gemm_args *args, vitk_stream_t stream);

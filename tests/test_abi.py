@@ -38,7 +38,7 @@ def test_vitk_argument_validation_reports_errors():
         vitk.call("vitk_layernorm_fwd", None, 4, 8, 4, None, None, 1e-5, None, None, None, None)  # stride < D
     with pytest.raises(vitk.VitkError):
         vitk.call("vitk_dropout_fwd", None, 4, 1.5, 0, 0, None, None, None)
-    assert C.sizeof(vitk.GemmArgs) == 200
+    assert C.sizeof(vitk.GemmArgs) == 208
 
 
 def test_vit_host_exports_every_declared_symbol():

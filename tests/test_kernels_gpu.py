@@ -422,6 +422,27 @@ def test_dk_reference_scatter(K):
     np.testing.assert_array_equal(host(out)[:, :h * dh], want)
 
 
+@pytest.mark.parametrize("M,N,Kd,split", [(96, 384, 640, 1), (96, 384, 640, 0), (768, 768, 6400, 0), (75, 130, 257, 1),
+                                          (192, 64, 8704, 0), (128, 128, 16, 1), (40, 10, 33, 4)])
+def test_gemm_fused_column_sums_of_b(K, M, N, Kd, split):
+    """dW = X^T dY with db = dY.sum(0) from the same launch (Dense::backward, src/layers/Dense.cpp:90-95)."""
+    x, dy = V.rng_normal(5, Kd, M), V.rng_normal(6, Kd, N)
+    dw, db = empty(M, N), torch.full((N,), np.nan, device="cuda")
+    K.gemm(dev(x), dev(dy), dw, M, N, Kd, trans_a=True, split_k=split, colsum_b=db)
+    close(host(dw), ref_gemm(x, dy, 1, 0), 1e-5)
+    close(host(db), dy.astype(np.float64).sum(0), 1e-5)
+    # same numbers without the fused sum
+    dw2 = empty(M, N)
+    K.gemm(dev(x), dev(dy), dw2, M, N, Kd, trans_a=True, split_k=split)
+    np.testing.assert_array_equal(host(dw), host(dw2))
+
+
+def test_gemm_column_sums_need_untransposed_b(K):
+    a, c, s = empty(8, 8), empty(8, 8), empty(8)
+    with pytest.raises(K.VitkError):
+        K.gemm(a, a, c, 8, 8, 8, trans_b=True, colsum_b=s)
+
+
 # ---------------------------------------- fused attention (vitk_sdpa_fwd / vitk_sdpa_bwd)
 def sdpa_numpy(q, k, v, do, scale):
     """float64 attention per (batch, head): q, k, v, do are [B][H][N][dh]."""

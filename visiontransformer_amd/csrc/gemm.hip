@@ -51,6 +51,8 @@ struct Params {
   int split_k, k_chunk;
   float *ws;
   int tiles_m, tiles_n, strip;
+  float *colsum;     // column sums of B (null = off); split-K: partial sums [split][N] in colsum_ws
+  float *colsum_ws;
   int vec_a, vec_b;
 #ifdef VITK_GEMM_STAMPS
   unsigned long long *stamps;  // diagnostic build only: 8 clock stamps per workgroup
@@ -337,8 +339,7 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
         lds_barrier();                                                                                      \
         VITK_SEG(1)                                                                                         \
         if ((STEADY || (T) + 2 < nslab) && VITK_DIAG_KEEP(2)) {                                             \
-          OpA::store(As + fre * SA, RA);                                                                    \
-          OpB::store(Bs + fre * SB, RB);                                                                    \
+          VITK_STAGE(fre, RA, RB)                                                                           \
         }                                                                                                   \
         VITK_SEG(2)                                                                                         \
         if ((STEADY || (T) + 4 < nslab) && VITK_DIAG_KEEP(4)) {                                             \
@@ -353,17 +354,25 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   }
 
   VITK_SEG_DECL()
+  // Column sums of B ride along: the workgroups of the first tile row add up what they stage.
+  const bool do_colsum = !TB && p.colsum != nullptr && tm == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#define VITK_STAGE(SLOT, RA, RB)                                                          \
+  OpA::store(As + (SLOT)*SA, RA);                                                         \
+  OpB::store(Bs + (SLOT)*SB, RB);                                                         \
+  if constexpr (!TB) {                                                                    \
+    if (do_colsum) { _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) csum += RB[it]; } \
+  }
+
   // Long contractions: a straight-line prologue and a condition-free steady state in ONE branch,
   // so the compiler counts the loads in flight exactly and a slab waits only for the older of
   // the two register sets.  Everything else (short contractions, the last slabs) takes the
   // guarded path below.
   if (nslab >= 6) {
     VITK_FETCH(0, ra0, rb0)
-    OpA::store(As, ra0);
-    OpB::store(Bs, rb0);
+    VITK_STAGE(0, ra0, rb0)
     VITK_FETCH(1, ra1, rb1)
-    OpA::store(As + SA, ra1);
-    OpB::store(Bs + SB, rb1);
+    VITK_STAGE(1, ra1, rb1)
     VITK_FETCH(2, ra0, rb0)
     VITK_FETCH(3, ra1, rb1)
     VITK_FIRST_OPERANDS()
@@ -374,13 +383,11 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   } else {
     if (nslab > 0) {
       VITK_FETCH(0, ra0, rb0)
-      OpA::store(As, ra0);
-      OpB::store(Bs, rb0);
+      VITK_STAGE(0, ra0, rb0)
     }
     if (nslab > 1) {
       VITK_FETCH(1, ra1, rb1)
-      OpA::store(As + SA, ra1);
-      OpB::store(Bs + SB, rb1);
+      VITK_STAGE(1, ra1, rb1)
     }
     if (nslab > 2) {
       VITK_FETCH(2, ra0, rb0)
@@ -396,9 +403,28 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   }
   VITK_SEG_FLUSH()
 #undef VITK_SLAB
+#undef VITK_STAGE
 #undef VITK_FIRST_OPERANDS
 #undef VITK_FETCH
   VITK_STAMP(2)
+
+  if constexpr (!TB) {
+    if (do_colsum) {  // workgroup-uniform
+      // Thread t summed rows t / (TILE/4) (+ multiples) of columns 4*(t % (TILE/4)) .. +3: add the
+      // THREADS / (TILE/4) row groups in a fixed order through LDS (the ring is free by now).
+      constexpr int QUADS = TILE / 4, GROUPS = THREADS / QUADS;
+      __syncthreads();
+      *reinterpret_cast<f32x4 *>(As + (threadIdx.x / QUADS) * TILE + 4 * (threadIdx.x % QUADS)) = csum;
+      __syncthreads();
+      if (threadIdx.x < TILE && n0 + (int)threadIdx.x < p.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) t += As[g * TILE + threadIdx.x];
+        if (p.split_k > 1) p.colsum_ws[(long long)z * p.N + n0 + threadIdx.x] = t;
+        else p.colsum[n0 + threadIdx.x] = t;
+      }
+    }
+  }
 
   const int row_w = m0 + wr * WT, col_w = n0 + wc * WT;  // this wave's sub-tile origin
 #ifdef VITK_GEMM_STAMPS
@@ -527,8 +553,15 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
 
 // C[b][m][n] = sum_s ws[b*S + s][m][n], s ascending (fixed order => reproducible).
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int S, int M, int N, float *__restrict__ C,
-                                     long long ldc, int batch_inner, long long sc_o, long long sc_i, long long total) {
+                                     long long ldc, int batch_inner, long long sc_o, long long sc_i, long long total,
+                                     const float *__restrict__ colsum_ws, float *__restrict__ colsum) {
   const long long mn = (long long)M * N;
+  if (colsum != nullptr)  // column sums of B: partials [S][N], same fixed order
+    for (long long n = blockIdx.x * (long long)blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+      float t = 0.f;
+      for (int k = 0; k < S; ++k) t += colsum_ws[(long long)k * N + n];
+      colsum[n] = t;
+    }
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const long long b = idx / mn, e = idx % mn;
@@ -642,7 +675,7 @@ extern "C" size_t vitk_gemm_workspace_bytes(const vitk_gemm_args *a) {
   Plan pl;
   make_plan(a, &pl);
   if (pl.split_k <= 1) return 0;
-  return (size_t)pl.split_k * pl.batch * a->M * a->N * sizeof(float);
+  return ((size_t)pl.split_k * pl.batch * a->M * a->N + (a->colsum_b ? (size_t)pl.split_k * a->N : 0)) * sizeof(float);
 }
 
 extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
@@ -663,7 +696,9 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   make_plan(a, &pl);
   const bool plain = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
   VITK_REQUIRE(pl.split_k == 1 || plain, "vitk_gemm_f32: split-K needs alpha == 1 and no bias/act/residual");
-  const size_t need = pl.split_k > 1 ? (size_t)pl.split_k * pl.batch * a->M * a->N * sizeof(float) : 0;
+  const size_t need = vitk_gemm_workspace_bytes(a);
+  VITK_REQUIRE(a->colsum_b == nullptr || (a->trans_b == 0 && pl.batch == 1),
+               "vitk_gemm_f32: colsum_b needs trans_b == 0 and batch == 1");
   VITK_REQUIRE(need == 0 || (a->workspace != nullptr && a->workspace_bytes >= need),
                "vitk_gemm_f32: split-K=%d needs %zu workspace bytes, got %zu", pl.split_k, need, a->workspace_bytes);
   VITK_REQUIRE((long long)pl.batch * pl.split_k <= 65535, "vitk_gemm_f32: batch*split_k = %lld exceeds grid limit",
@@ -680,6 +715,8 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   p.sc_o = a->stride_c_outer; p.sc_i = a->stride_c_inner;
   p.split_k = pl.split_k; p.k_chunk = pl.k_chunk; p.ws = a->workspace;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.colsum = a->colsum_b;
+  p.colsum_ws = pl.split_k > 1 && a->colsum_b ? a->workspace + (size_t)pl.split_k * pl.batch * a->M * a->N : nullptr;
   {  // column strips of at most 8 tiles, as even as possible
     static const int strip_env = getenv("VITK_GEMM_STRIP") ? atoi(getenv("VITK_GEMM_STRIP")) : 8;
     const int nstrips = (pl.tiles_n + strip_env - 1) / strip_env;
@@ -721,7 +758,7 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   if (pl.split_k > 1) {
     const long long total = (long long)pl.batch * a->M * a->N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(vitk::grid_for(total, 256)), dim3(256), 0, st, a->workspace,
-                       pl.split_k, a->M, a->N, a->C, a->ldc, p.batch_inner, p.sc_o, p.sc_i, total);
+                       pl.split_k, a->M, a->N, a->C, a->ldc, p.batch_inner, p.sc_o, p.sc_i, total, p.colsum_ws, p.colsum);
     if (vitk::check_launch("vitk_gemm_f32/splitk_reduce")) return 1;
   }
   return 0;

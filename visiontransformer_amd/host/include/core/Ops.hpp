@@ -42,6 +42,7 @@ struct GemmOpts {
   int batch_outer = 1, batch_inner = 1;
   int64_t sa_o = 0, sa_i = 0, sb_o = 0, sb_i = 0, sc_o = 0, sc_i = 0;
   int split_k = 1;  // 0 = let the library split the contraction (weight gradients)
+  float *colsum_b = nullptr;  // also produce the column sums of B (bias gradient next to dW = X^T dY)
 };
 
 void gemm(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,

@@ -176,7 +176,7 @@ Tensor MultiHeadAttention::backward(const Tensor &outputGradient) {
   return projectionBackward(dqkv);
 }
 
-// packed projection backward: dW_qkv = X^T dQKV, db_qkv = colsum, dX = dQKV W_qkv^T
+// packed projection backward: dW_qkv = X^T dQKV (+ db_qkv = column sums, same launch), dX = dQKV W_qkv^T
 Tensor MultiHeadAttention::projectionBackward(const Tensor &dqkv) {
   const auto &s = inputTensor.getShape();
   const int64_t D = (int64_t)embedding_dim, M = (int64_t)(s[0] * s[1]);
@@ -185,9 +185,9 @@ Tensor MultiHeadAttention::projectionBackward(const Tensor &dqkv) {
   {
     GemmOpts o;
     o.split_k = 0;
+    o.colsum_b = dbqkv.deviceData();
     vit::gemm(true, false, D, 3 * D, M, x, D, dq, 3 * D, dwqkv.deviceData(), 3 * D, o);
   }
-  vit::colsum(dq, M, 3 * D, 3 * D, dbqkv.deviceData());
   Tensor dx = Tensor::deviceEmpty(inputTensor.getShape());
   vit::gemm(false, true, M, D, 3 * D, dq, 3 * D, wqkv.deviceData(), 3 * D, dx.deviceDataOverwrite(), D);
   return dx;

@@ -81,13 +81,13 @@ Tensor Dense::backwardFused(const Tensor &outputGradient, int act, const Tensor 
   Tensor dy = outputGradient.dense();
   const size_t rows = inputTensor.getSize() / in;
   if (dy.getSize() != rows * out) throw std::runtime_error("Dense::backward: forma de gradiente incompatible.");
-  // dW = X^T dY : contraction over all rows; the library splits it over the chip
+  // dW = X^T dY : contraction over all rows; the library splits it over the chip.  db = dY.sum(0)
+  // is accumulated by the same launch from the dY tiles it stages.
   GemmOpts ow;
   ow.split_k = 0;
+  ow.colsum_b = biasGradients.deviceData();
   vit::gemm(true, false, (int64_t)in, (int64_t)out, (int64_t)rows, inputTensor.deviceData(), (int64_t)in,
             dy.deviceData(), (int64_t)out, weightGradients.deviceData(), (int64_t)weightGradients.getStrides()[0], ow);
-  // db = dY.sum(0)
-  vit::colsum(dy.deviceData(), (int64_t)rows, (int64_t)out, (int64_t)out, biasGradients.deviceData());
   if (!needInputGrad) return Tensor();
   // dX = dY W^T
   Tensor dx = Tensor::deviceEmpty(inputTensor.getShape());

@@ -42,6 +42,7 @@ void gemm(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const flo
   g.stride_b_outer = o.sb_o; g.stride_b_inner = o.sb_i;
   g.stride_c_outer = o.sc_o; g.stride_c_inner = o.sc_i;
   g.split_k = o.split_k;
+  g.colsum_b = o.colsum_b;
   const size_t wsb = vitk_gemm_workspace_bytes(&g);
   if (wsb) {
     g.workspace = workspace(wsb);

@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
         ("stride_b_outer", C.c_int64), ("stride_b_inner", C.c_int64),
         ("stride_c_outer", C.c_int64), ("stride_c_inner", C.c_int64),
         ("split_k", C.c_int32), ("reserved", C.c_int32),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colsum_b", C.c_void_p),
     ]
 
 
@@ -131,7 +131,7 @@ def init(device=0):
 
 def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, alpha=1.0,
          act=ACT_NONE, bias=None, residual=None, ldr=None, aux=None, ldaux=None, batch_outer=1, batch_inner=1,
-         stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), split_k=1, workspace=None, st=None):
+         stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), split_k=1, workspace=None, st=None, colsum_b=None):
     """C = epilogue(alpha * op(A) op(B)); see include/vitk.h.  With split_k != 1 and no workspace given,
     one is allocated with torch (tests only; the host layer passes its own)."""
     a = GemmArgs()
@@ -149,6 +149,7 @@ def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=Non
     a.stride_b_outer, a.stride_b_inner = stride_b
     a.stride_c_outer, a.stride_c_inner = stride_c
     a.split_k = split_k
+    a.colsum_b = ptr(colsum_b)
     need = dll().vitk_gemm_workspace_bytes(C.byref(a))
     keep = None
     if need:
