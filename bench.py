@@ -85,6 +85,16 @@ def cpu_baseline(cfgd, seconds_budget=30.0):
                       f"(forward + CE + backward + Adam), {el:.1f} s of host time, OpenMP threads = {cores}"}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this same command
+    (rocprofv3 cannot collect counters from inside a timed run); None if there is no profile."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +193,9 @@ def main():
                        "patch_mode": "im2col", "params": int(model.n), "final_loss": round(float(loss), 6)},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": None,
+                         "traffic": measured_traffic(dom["name"]),
+                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes of this command "
+                                         "(profiles/r01_hbm_traffic.json); algorithmic operand bytes in DESIGN.md",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                          "flops_per_launch": dom["flops"] / dom["launches"],
                          "all_gemm_ms_per_step": round(gemm_ms / args.steps, 3),
