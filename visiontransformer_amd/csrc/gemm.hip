@@ -607,7 +607,7 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
   const bool plain0 = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
   const long long t128 = (long long)((a->M + 127) / 128) * ((a->N + 127) / 128) * pl->batch;
   const bool can_split = plain0 && a->split_k != 1 && a->K >= 4096;
-  pl->tile = (a->M >= 128 && a->N >= 128 && (t128 >= 64 || can_split)) ? 128 : 64;
+  pl->tile = (a->reserved != 1 && a->M >= 128 && a->N >= 128 && (t128 >= 64 || can_split)) ? 128 : 64;
   pl->tiles_m = (a->M + pl->tile - 1) / pl->tile;
   pl->tiles_n = (a->N + pl->tile - 1) / pl->tile;
   const bool plain = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
@@ -696,6 +696,34 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   make_plan(a, &pl);
   const bool plain = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
   VITK_REQUIRE(pl.split_k == 1 || plain, "vitk_gemm_f32: split-K needs alpha == 1 and no bias/act/residual");
+
+  // Tail round.  The chip holds 256 x kBlocksPerCU workgroups; when the tile count leaves a small
+  // remainder after the last full round (N = 768: 394 x 6 tiles = 3 rounds + 60), those few 128-wide
+  // tiles would each run alone on a CU while most CUs idle.  Cut the trailing tile rows off and run
+  // them as a second launch, which make_plan covers with four times as many 64-wide tiles.
+  static const bool tail_split = getenv("VITK_GEMM_NO_TAIL_SPLIT") == nullptr;
+  if (tail_split && a->reserved == 0 && pl.tile == 128 && pl.split_k == 1 && pl.batch == 1 &&
+      a->colsum_b == nullptr) {
+    const int slots = 256 * kBlocksPerCU;
+    static const int tail_max = getenv("VITK_GEMM_TAIL_MAX") ? atoi(getenv("VITK_GEMM_TAIL_MAX")) : 128;
+    const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
+    const int head_rows = (int)(tiles / slots * slots / pl.tiles_n);  // tile rows inside the full rounds
+    const int tail_rows = pl.tiles_m - head_rows;
+    if (head_rows > 0 && tail_rows > 0 && tail_rows * pl.tiles_n <= tail_max && a->M % 128 == 0) {
+      const int m_head = head_rows * 128;
+      vitk_gemm_args head = *a, tail = *a;
+      head.M = m_head;
+      tail.M = a->M - m_head;
+      tail.A = a->A + (a->trans_a ? (int64_t)m_head : (int64_t)m_head * a->lda);
+      tail.C = a->C + (int64_t)m_head * a->ldc;
+      if (a->residual) tail.residual = a->residual + (int64_t)m_head * a->ldr;
+      if (a->aux) tail.aux = a->aux + (int64_t)m_head * a->ldaux;
+      tail.reserved = 1;  // 64-wide tiles, no further splitting
+      if (vitk_gemm_f32(&head, stream)) return 1;
+      return vitk_gemm_f32(&tail, stream);
+    }
+  }
+
   const size_t need = vitk_gemm_workspace_bytes(a);
   VITK_REQUIRE(a->colsum_b == nullptr || (a->trans_b == 0 && pl.batch == 1),
                "vitk_gemm_f32: colsum_b needs trans_b == 0 and batch == 1");
