@@ -56,33 +56,35 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // Cooperative 32-row x DHP tile of a [N][ld] matrix (head columns), zero-filled outside
-// (rows >= N, columns >= dh).  Thread t holds PER consecutive columns of row t/8.
-template <int DHP>
+// (rows >= N, columns >= dh).  Thread t holds PER consecutive columns of row t/8.  Loads are
+// branch-free (clamped address + select) so that they stay in flight until their LDS store.
+// VEC: all pointers 16-byte aligned, all pitches and dh multiples of 4.
+template <int DHP, bool VEC>
 struct Tile {
   static constexpr int PER = DHP / 8;
   static constexpr int PW = DHP >= 32 ? DHP : 32;  // pitch of a plain tile [32 rows][d]
   static constexpr int PLAIN = 32 * PW, TRANS = DHP * PT;
-  __device__ static void load(const float *__restrict__ base, long long ld, int row0, int N, int dh, bool vec,
-                              float (&r)[PER]) {
+  __device__ static void load(const float *__restrict__ base, long long ld, int row0, int N, int dh, float (&r)[PER]) {
     const int row = row0 + (threadIdx.x >> 3), c0 = (threadIdx.x & 7) * PER;
+    const bool row_ok = row < N;
+    const float *p = base + (long long)min(row, N - 1) * ld;
+    if constexpr (VEC && PER >= 4) {
 #pragma unroll
-    for (int e = 0; e < PER; ++e) r[e] = 0.f;
-    if (row >= N) return;
-    const float *p = base + (long long)row * ld + c0;
-    if constexpr (PER >= 4) {
-      if (vec) {
+      for (int v = 0; v < PER / 4; ++v) {
+        const int c = c0 + 4 * v;
+        const bool ok = row_ok && c < dh;
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(p + (c < dh ? c : 0));
 #pragma unroll
-        for (int v = 0; v < PER / 4; ++v)
-          if (c0 + 4 * v < dh) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * v);
-            r[4 * v] = t.x; r[4 * v + 1] = t.y; r[4 * v + 2] = t.z; r[4 * v + 3] = t.w;
-          }
-        return;
+        for (int e = 0; e < 4; ++e) r[4 * v + e] = ok ? t[e] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        const int c = c0 + e;
+        const float t = p[c < dh ? c : 0];
+        r[e] = (row_ok && c < dh) ? t : 0.f;
       }
     }
-#pragma unroll
-    for (int e = 0; e < PER; ++e)
-      if (c0 + e < dh) r[e] = p[e];
   }
   __device__ static void store_plain(float *__restrict__ dst, const float (&r)[PER]) {
     float *d = dst + (threadIdx.x >> 3) * PW + (threadIdx.x & 7) * PER;
@@ -105,40 +107,40 @@ struct Tile {
 };
 
 // One lane's operand fragment of its own row: X[row][(DHP/2)*lh + j], j < DHP/2 (zero outside).
-template <int DHP>
+template <int DHP, bool VEC>
 __device__ __forceinline__ void load_fragment(const float *__restrict__ base, long long ld, int row, int N, int dh,
-                                              bool vec, int lh, float (&f)[DHP / 2]) {
+                                              int lh, float (&f)[DHP / 2]) {
   constexpr int HALF = DHP / 2;
+  const bool row_ok = row < N;
+  const float *p = base + (long long)min(row, N - 1) * ld;
+  if constexpr (VEC && HALF % 4 == 0) {
 #pragma unroll
-  for (int j = 0; j < HALF; ++j) f[j] = 0.f;
-  if (row >= N) return;
-  const float *p = base + (long long)row * ld + HALF * lh;
-  if constexpr (HALF % 4 == 0) {
-    if (vec) {
+    for (int v = 0; v < HALF / 4; ++v) {
+      const int c = HALF * lh + 4 * v;
+      const bool ok = row_ok && c < dh;
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(p + (c < dh ? c : 0));
 #pragma unroll
-      for (int v = 0; v < HALF / 4; ++v)
-        if (HALF * lh + 4 * v < dh) {
-          const f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * v);
-          f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
-        }
-      return;
+      for (int e = 0; e < 4; ++e) f[4 * v + e] = ok ? t[e] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) {
+      const int c = HALF * lh + j;
+      const float t = p[c < dh ? c : 0];
+      f[j] = (row_ok && c < dh) ? t : 0.f;
     }
   }
-#pragma unroll
-  for (int j = 0; j < HALF; ++j)
-    if (HALF * lh + j < dh) f[j] = p[j];
 }
 
 // Store a transposed result tile set acc[t][4g+e] = X^T[d = 32t + 8g + 4lh + e][row li] as row `row`.
-template <int DT>
-__device__ __forceinline__ void store_rows(float *__restrict__ rowp, const f32x16 (&acc)[DT], int dh, bool vec,
-                                           int lh) {
+template <int DT, bool VEC>
+__device__ __forceinline__ void store_rows(float *__restrict__ rowp, const f32x16 (&acc)[DT], int dh, int lh) {
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int d0 = 32 * t + 8 * g + 4 * lh;
-      if (vec) {
+      if constexpr (VEC) {
         if (d0 < dh) {
           const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
           *reinterpret_cast<f32x4 *>(rowp + d0) = v;
@@ -157,9 +159,9 @@ __device__ __forceinline__ void store_rows(float *__restrict__ rowp, const f32x1
 // Pass 1 streams the key tiles and accumulates the whole score row block S^T[key][query] of the
 // wave (NKT tiles x 16 registers); softmax runs on registers (a row lives in one lane pair);
 // pass 2 streams the value tiles and accumulates O^T[d][query] with the probabilities as operand B.
-template <int DHP, int NKT>
+template <int DHP, int NKT, bool VEC>
 __global__ __launch_bounds__(THREADS, 2) void sdpa_fwd_kernel(const SdpaParams p) {
-  using T = Tile<DHP>;
+  using T = Tile<DHP, VEC>;
   constexpr int HALF = DHP / 2, DT = DHP >= 32 ? DHP / 32 : 1, PW = T::PW;
   constexpr int STAGE = T::TRANS > T::PLAIN ? T::TRANS : T::PLAIN;
   __shared__ __attribute__((aligned(16))) float ring[2 * STAGE];
@@ -172,27 +174,26 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_fwd_kernel(const SdpaParams p
   const int nkt = (p.N + 31) / 32;
   const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
   const float *Q = p.q + head, *K = p.k + head, *V = p.v + head;
-  const bool vec = p.vec != 0;
   if constexpr (DHP < 32) {  // padding columns of the plain tiles stay zero
     for (int i = threadIdx.x; i < 2 * STAGE; i += THREADS) ring[i] = 0.f;
     __syncthreads();
   }
 
   float qf[HALF];
-  load_fragment<DHP>(Q, p.ld, q0 + li, p.N, p.dh, vec, lh, qf);
+  load_fragment<DHP, VEC>(Q, p.ld, q0 + li, p.N, p.dh, lh, qf);
 
   f32x16 s[NKT];
 #pragma unroll
   for (int j = 0; j < NKT; ++j) s[j] = zero16();
   float lr[T::PER];
-  T::load(K, p.ld, 0, p.N, p.dh, vec, lr);
+  T::load(K, p.ld, 0, p.N, p.dh, lr);
   T::store_trans(ring, lr);
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < NKT; ++j) {
     if (j < nkt) {
-      if (j + 1 < nkt) T::load(K, p.ld, 32 * (j + 1), p.N, p.dh, vec, lr);
-      else T::load(V, p.ld, 0, p.N, p.dh, vec, lr);
+      const bool more_keys = j + 1 < nkt;  // next in the stream: key tile j+1, or value tile 0
+      T::load(more_keys ? K : V, p.ld, more_keys ? 32 * (j + 1) : 0, p.N, p.dh, lr);
       if (active) {
         const float *ks = ring + (j & 1) * STAGE + (HALF * lh) * PT + li;
 #pragma unroll
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_fwd_kernel(const SdpaParams p
           s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[jj * PT], qf[jj], s[j], 0, 0, 0);
       }
       float *nxt = ring + ((j + 1) & 1) * STAGE;
-      if (j + 1 < nkt) T::store_trans(nxt, lr);
+      if (more_keys) T::store_trans(nxt, lr);
       else T::store_plain(nxt, lr);
       __syncthreads();
     }
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_fwd_kernel(const SdpaParams p
 #pragma unroll
   for (int j = 0; j < NKT; ++j) {
     if (j < nkt) {
-      if (j + 1 < nkt) T::load(V, p.ld, 32 * (j + 1), p.N, p.dh, vec, lr);
+      if (j + 1 < nkt) T::load(V, p.ld, 32 * (j + 1), p.N, p.dh, lr);
       if (active) {
         const float *vs = ring + ((nkt + j) & 1) * STAGE + (4 * lh) * PW + li;
 #pragma unroll
@@ -260,15 +261,15 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_fwd_kernel(const SdpaParams p
     }
   }
   if (active && q0 + li < p.N)
-    store_rows<DT>(p.out + ((long long)b * p.N + q0 + li) * p.ldo + (long long)h * p.dh, o, p.dh, vec, lh);
+    store_rows<DT, VEC>(p.out + ((long long)b * p.N + q0 + li) * p.ldo + (long long)h * p.dh, o, p.dh, lh);
 }
 
 // ---- backward, query side: dQ (and dsum = rowsum(dO*O) for the key side) --------------------------
 // Per key tile: S^T = K Q^T and dP^T = V dO^T (both [key][query]), P from the saved row statistics,
 // dS^T = P^T (dP^T - dsum) * scale, dQ^T[d][query] += K^T dS^T with dS^T as operand B.
-template <int DHP>
+template <int DHP, bool VEC>
 __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dq_kernel(const SdpaParams p) {
-  using T = Tile<DHP>;
+  using T = Tile<DHP, VEC>;
   constexpr int HALF = DHP / 2, DT = DHP >= 32 ? DHP / 32 : 1, PW = T::PW;
   constexpr int STAGE = 2 * T::TRANS + T::PLAIN;  // K^T, V^T, K
   __shared__ __attribute__((aligned(16))) float ring[2 * STAGE];
@@ -282,19 +283,18 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dq_kernel(const SdpaParam
   const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
   const long long ohead = (long long)b * p.N * p.ldo + (long long)h * p.dh;
   const float *Q = p.q + head, *K = p.k + head, *V = p.v + head;
-  const bool vec = p.vec != 0;
   if constexpr (DHP < 32) {
     for (int i = threadIdx.x; i < 2 * STAGE; i += THREADS) ring[i] = 0.f;
     __syncthreads();
   }
 
   float qf[HALF], dof[HALF];
-  load_fragment<DHP>(Q, p.ld, q, p.N, p.dh, vec, lh, qf);
-  load_fragment<DHP>(p.dout + ohead, p.ldo, q, p.N, p.dh, vec, lh, dof);
+  load_fragment<DHP, VEC>(Q, p.ld, q, p.N, p.dh, lh, qf);
+  load_fragment<DHP, VEC>(p.dout + ohead, p.ldo, q, p.N, p.dh, lh, dof);
   float dsum = 0.f, m = 0.f, inv = 0.f;
   if (active) {
     float of[HALF];
-    load_fragment<DHP>(p.o + ohead, p.ldo, q, p.N, p.dh, vec, lh, of);
+    load_fragment<DHP, VEC>(p.o + ohead, p.ldo, q, p.N, p.dh, lh, of);
 #pragma unroll
     for (int j = 0; j < HALF; ++j) dsum += dof[j] * of[j];
     dsum += __shfl_xor(dsum, 32, 64);
@@ -310,16 +310,16 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dq_kernel(const SdpaParam
 #pragma unroll
   for (int t = 0; t < DT; ++t) dq[t] = zero16();
   float kr[T::PER], vr[T::PER];
-  T::load(K, p.ld, 0, p.N, p.dh, vec, kr);
-  T::load(V, p.ld, 0, p.N, p.dh, vec, vr);
+  T::load(K, p.ld, 0, p.N, p.dh, kr);
+  T::load(V, p.ld, 0, p.N, p.dh, vr);
   T::store_trans(ring, kr);
   T::store_trans(ring + T::TRANS, vr);
   T::store_plain(ring + 2 * T::TRANS, kr);
   __syncthreads();
   for (int j = 0; j < nkt; ++j) {
     if (j + 1 < nkt) {
-      T::load(K, p.ld, 32 * (j + 1), p.N, p.dh, vec, kr);
-      T::load(V, p.ld, 32 * (j + 1), p.N, p.dh, vec, vr);
+      T::load(K, p.ld, 32 * (j + 1), p.N, p.dh, kr);
+      T::load(V, p.ld, 32 * (j + 1), p.N, p.dh, vr);
     }
     if (active) {
       const float *st = ring + (j & 1) * STAGE;
@@ -352,21 +352,21 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dq_kernel(const SdpaParam
     __syncthreads();
   }
   if (active && q < p.N)
-    store_rows<DT>(p.dq + ((long long)b * p.N + q) * p.ldg + (long long)h * p.dh, dq, p.dh, vec, lh);
+    store_rows<DT, VEC>(p.dq + ((long long)b * p.N + q) * p.ldg + (long long)h * p.dh, dq, p.dh, lh);
 }
 
 template <int DHP>
 struct DkvStage {
-  static constexpr int value = 2 * Tile<DHP>::TRANS + 2 * Tile<DHP>::PLAIN + 96;
+  static constexpr int value = 2 * Tile<DHP, true>::TRANS + 2 * Tile<DHP, true>::PLAIN + 96;
 };
 
 // ---- backward, key side: dK and dV ----------------------------------------------------------------
 // Per query tile: S = Q K^T and dP = dO V^T (both [query][key]), P, dS as above (row statistics
 // come from LDS: the query index is the register index here), then
 // dV^T[d][key] += dO^T P and dK^T[d][key] += Q^T dS with P / dS as operand B.
-template <int DHP>
+template <int DHP, bool VEC>
 __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaParams p) {
-  using T = Tile<DHP>;
+  using T = Tile<DHP, VEC>;
   constexpr int HALF = DHP / 2, DT = DHP >= 32 ? DHP / 32 : 1, PW = T::PW;
   constexpr int STAGE = DkvStage<DHP>::value;  // Q^T, dO^T, Q, dO, {max, 1/sum, dsum}[32]
   extern __shared__ __attribute__((aligned(16))) float ring[];  // 2 * STAGE floats (above 64 KB for dh = 64)
@@ -380,32 +380,32 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaPara
   const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
   const long long ohead = (long long)b * p.N * p.ldo + (long long)h * p.dh;
   const float *Q = p.q + head, *K = p.k + head, *V = p.v + head, *DO = p.dout + ohead;
-  const bool vec = p.vec != 0;
   if constexpr (DHP < 32) {
     for (int i = threadIdx.x; i < 2 * STAGE; i += THREADS) ring[i] = 0.f;
     __syncthreads();
   }
 
   float kf[HALF], vf[HALF];
-  load_fragment<DHP>(K, p.ld, key, p.N, p.dh, vec, lh, kf);
-  load_fragment<DHP>(V, p.ld, key, p.N, p.dh, vec, lh, vf);
+  load_fragment<DHP, VEC>(K, p.ld, key, p.N, p.dh, lh, kf);
+  load_fragment<DHP, VEC>(V, p.ld, key, p.N, p.dh, lh, vf);
   const bool key_ok = key < p.N;
 
   f32x16 dk[DT], dv[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t) dk[t] = zero16(), dv[t] = zero16();
-  float qr[T::PER], gr[T::PER], sm = 0.f, si = 0.f, sd = 0.f;
-  // row statistics of a query tile: threads 0..31 fetch {max, 1/sum, dsum} of query 32*i + t
+  float qr[T::PER], gr[T::PER];
+  // row statistics {max, sum, dsum} of query 32*i + (t & 31): fetched branch-free by every thread
+  // (clamped index), finished and written to LDS by threads 0..31 when the stage is stored
+  float st_max = 0.f, st_sum = 1.f, st_dsum = 0.f;
+  bool st_ok = false;
 #define VITK_LOAD_STATS(I)                                                    \
-  if (threadIdx.x < 32) {                                                     \
-    const int qq = 32 * (I) + threadIdx.x;                                    \
-    sm = 0.f, si = 0.f, sd = 0.f;                                             \
-    if (qq < p.N) {                                                           \
-      const float *st = p.stats + ((long long)bh * p.N + qq) * 2;             \
-      sm = st[0];                                                             \
-      si = 1.0f / st[1];                                                      \
-      sd = p.dsum[(long long)bh * p.N + qq];                                  \
-    }                                                                         \
+  {                                                                           \
+    const int qq = 32 * (I) + (threadIdx.x & 31);                             \
+    const long long at = (long long)bh * p.N + min(qq, p.N - 1);              \
+    st_ok = qq < p.N;                                                         \
+    st_max = p.stats[at * 2];                                                 \
+    st_sum = p.stats[at * 2 + 1];                                             \
+    st_dsum = p.dsum[at];                                                     \
   }
 #define VITK_STORE_STAGE(DST)                                                 \
   {                                                                           \
@@ -416,20 +416,20 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaPara
     T::store_plain(nx + 2 * T::TRANS + T::PLAIN, gr);                         \
     if (threadIdx.x < 32) {                                                   \
       float *ss = nx + 2 * T::TRANS + 2 * T::PLAIN;                           \
-      ss[threadIdx.x] = sm;                                                   \
-      ss[32 + threadIdx.x] = si;                                              \
-      ss[64 + threadIdx.x] = sd;                                              \
+      ss[threadIdx.x] = st_ok ? st_max : 0.f;                                 \
+      ss[32 + threadIdx.x] = st_ok ? 1.0f / st_sum : 0.f;                     \
+      ss[64 + threadIdx.x] = st_ok ? st_dsum : 0.f;                           \
     }                                                                         \
   }
-  T::load(Q, p.ld, 0, p.N, p.dh, vec, qr);
-  T::load(DO, p.ldo, 0, p.N, p.dh, vec, gr);
+  T::load(Q, p.ld, 0, p.N, p.dh, qr);
+  T::load(DO, p.ldo, 0, p.N, p.dh, gr);
   VITK_LOAD_STATS(0)
   VITK_STORE_STAGE(ring)
   __syncthreads();
   for (int i = 0; i < nqt; ++i) {
     if (i + 1 < nqt) {
-      T::load(Q, p.ld, 32 * (i + 1), p.N, p.dh, vec, qr);
-      T::load(DO, p.ldo, 32 * (i + 1), p.N, p.dh, vec, gr);
+      T::load(Q, p.ld, 32 * (i + 1), p.N, p.dh, qr);
+      T::load(DO, p.ldo, 32 * (i + 1), p.N, p.dh, gr);
       VITK_LOAD_STATS(i + 1)
     }
     if (active) {
@@ -470,9 +470,9 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaPara
 #undef VITK_LOAD_STATS
 #undef VITK_STORE_STAGE
   if (!active || !key_ok) return;
-  store_rows<DT>(p.dv + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dv, p.dh, vec, lh);
+  store_rows<DT, VEC>(p.dv + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dv, p.dh, lh);
   if (p.dk_mode == VITK_DK_EXACT) {
-    store_rows<DT>(p.dk + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dk, p.dh, vec, lh);
+    store_rows<DT, VEC>(p.dk + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dk, p.dh, lh);
   } else {
     // The reference forms Q^T dS as [dh][N] per head and re-reads that buffer as [N][dh]
     // (src/layers/MultiHeadAttention.cpp:207-222): element (d, key) lands at flat index d*N + key.
@@ -490,29 +490,30 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaPara
   }
 }
 
-template <int DHP>
+template <int DHP, bool VEC>
 int launch_fwd(const SdpaParams &p, int grid, hipStream_t st) {
   const int nkt = (p.N + 31) / 32;
-  if (nkt <= 1) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 1>), dim3(grid), dim3(THREADS), 0, st, p);
-  else if (nkt <= 2) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 2>), dim3(grid), dim3(THREADS), 0, st, p);
-  else if (nkt <= 4) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 4>), dim3(grid), dim3(THREADS), 0, st, p);
-  else if (nkt <= 7) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 7>), dim3(grid), dim3(THREADS), 0, st, p);  // 224/16
-  else hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 8>), dim3(grid), dim3(THREADS), 0, st, p);
+  const dim3 g(grid), b(THREADS);
+  if (nkt <= 1) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 1, VEC>), g, b, 0, st, p);
+  else if (nkt <= 2) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 2, VEC>), g, b, 0, st, p);
+  else if (nkt <= 4) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 4, VEC>), g, b, 0, st, p);
+  else if (nkt <= 7) hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 7, VEC>), g, b, 0, st, p);  // 224 / 16 patches + CLS
+  else hipLaunchKernelGGL((sdpa_fwd_kernel<DHP, 8, VEC>), g, b, 0, st, p);
   return vitk::check_launch("vitk_sdpa_fwd");
 }
 
-template <int DHP>
+template <int DHP, bool VEC>
 int launch_bwd(const SdpaParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = 2 * DkvStage<DHP>::value * sizeof(float);
   static bool configured = false;  // raise the dynamic LDS limit once per instantiation
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd_dkv_kernel<DHP>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd_dkv_kernel<DHP, VEC>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     VITK_REQUIRE(e == hipSuccess, "vitk_sdpa_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((sdpa_bwd_dq_kernel<DHP>), grid, dim3(THREADS), 0, st, p);
-  hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<DHP>), grid, dim3(THREADS), lds, st, p);
+  hipLaunchKernelGGL((sdpa_bwd_dq_kernel<DHP, VEC>), grid, dim3(THREADS), 0, st, p);
+  hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<DHP, VEC>), grid, dim3(THREADS), lds, st, p);
   return vitk::check_launch("vitk_sdpa_bwd");
 }
 
@@ -544,9 +545,12 @@ int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale;
   p.vec = all_vec({q, k, v, out}, {ld_qkv, ld_out, dh});
   hipStream_t st = vitk::as_stream(stream);
-  if (dh <= 16) return launch_fwd<16>(p, (int)blocks, st);
-  if (dh <= 32) return launch_fwd<32>(p, (int)blocks, st);
-  return launch_fwd<64>(p, (int)blocks, st);
+  // 16-byte accesses where every pointer, pitch and dh allow them (all ViT configurations); the
+  // scalar variant exists once, at the full 64-wide head tile
+  if (!p.vec) return launch_fwd<64, false>(p, (int)blocks, st);
+  if (dh <= 16) return launch_fwd<16, true>(p, (int)blocks, st);
+  if (dh <= 32) return launch_fwd<32, true>(p, (int)blocks, st);
+  return launch_fwd<64, true>(p, (int)blocks, st);
 }
 
 size_t vitk_sdpa_bwd_workspace_bytes(int32_t B, int32_t H, int32_t N) {
@@ -577,9 +581,10 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   p.vec = all_vec({q, k, v, out, dout, dq, dk, dv}, {ld_qkv, ld_out, ld_dqkv, dh});
   hipStream_t st = vitk::as_stream(stream);
   const dim3 grid((unsigned)blocks);
-  if (dh <= 16) return launch_bwd<16>(p, grid, st);
-  if (dh <= 32) return launch_bwd<32>(p, grid, st);
-  return launch_bwd<64>(p, grid, st);
+  if (!p.vec) return launch_bwd<64, false>(p, grid, st);
+  if (dh <= 16) return launch_bwd<16, true>(p, grid, st);
+  if (dh <= 32) return launch_bwd<32, true>(p, grid, st);
+  return launch_bwd<64, true>(p, grid, st);
 }
 
 }  // extern "C"
