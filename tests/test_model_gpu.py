@@ -344,3 +344,69 @@ def test_model_vs_oracle_at_baseline_shapes(H, name, B):
         k = int(np.prod(shp))
         close(grads[off:off + k], want_g[off:off + k], GRAD_TOL, f"grad tensor {i} {shp}")
         off += k
+
+
+# ---------------------------------------------------- the benchmark configuration at full size
+VIT_B16 = dict(image_size=224, patch_size=16, in_channels=3, num_classes=1000, embedding_dim=768, num_heads=12,
+               num_layers=12, mlp_hidden_dim=3072)
+
+
+def test_vit_b16_full_batch_two_attention_paths_agree_and_step_is_reproducible(H):
+    """ViT-B/16 at the benchmark's batch of 256 (too large for the CPU oracle, which needs hours
+    per step): the properties that do not depend on size.  (1) The two independent attention
+    implementations -- fused kernels vs batched contractions + row softmax -- give the same loss
+    and the same gradient for every parameter tensor (1e-4 of the tensor's max magnitude).
+    (2) Random-init loss is ln(1000) + var(logit)/2 (logits of a N(0, 0.02) head on unit-variance
+    normalised features: var = 768 * 0.02^2).  (3) Repeating the step
+    reproduces the gradients bit for bit (fixed-order split-K, column sums and reductions; no
+    atomics anywhere on the path).  (4) One Adam step moves every parameter tensor."""
+    from visiontransformer_amd import vitk
+    B = 256
+    cfg = hcfg(H, VIT_B16)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(B, 3, 224, 224, device="cuda", generator=g)
+    labels = torch.randint(0, 1000, (B,), device="cuda", generator=g)
+    y = torch.nn.functional.one_hot(labels, 1000).to(torch.float32).contiguous()
+
+    def run(fused):
+        H.set_fused_attention(fused)
+        try:
+            H.seed(99)
+            m = H.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
+        finally:
+            H.set_fused_attention(True)
+        t = H.Trainer(m, weight_decay=1e-4)
+        t.step_forward(x, y)
+        for s in range(t.num_stages):
+            t.backward_stage(s)
+        loss, _ = t.result()
+        return m, t, loss, m.get_grads()
+
+    m1, t1, loss1, g1 = run(True)
+    assert abs(loss1 - (np.log(1000.0) + 0.5 * 768 * 0.02 ** 2)) < 0.05, loss1
+    # (3) same step again on the same model: bit-identical gradients
+    t1.step_forward(x, y)
+    for s in range(t1.num_stages):
+        t1.backward_stage(s)
+    np.testing.assert_array_equal(m1.get_grads(), g1)
+    # (4) Adam moves every tensor
+    p0 = m1.get_params()
+    t1.train_step(x, y, 3e-4)
+    p1 = m1.get_params()
+    shapes = m1.param_shapes()
+    off = 0
+    for i, shp in enumerate(shapes):
+        k = int(np.prod(shp))
+        assert np.isfinite(p1[off:off + k]).all() and (p1[off:off + k] != p0[off:off + k]).any(), (i, shp)
+        off += k
+    del m1, t1
+    torch.cuda.empty_cache()
+    # (1) the unfused path, same seed => same initial weights
+    m2, t2, loss2, g2 = run(False)
+    assert abs(loss2 - loss1) <= 1e-5 * abs(loss1), (loss1, loss2)
+    off = 0
+    for i, shp in enumerate(shapes):
+        k = int(np.prod(shp))
+        e = V.max_relerr(g1[off:off + k], g2[off:off + k], floor=1e-7)
+        assert e <= 1e-4, f"grad tensor {i} {shp}: fused vs unfused attention {e:.3e}"
+        off += k
