@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="dropout rate (0 = the headline/parity configuration; 0.1 adds the device RNG cost)")
     args = ap.parse_args()
 
     import numpy as np
@@ -129,7 +131,7 @@ def main():
     cfgd, batch = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    cfg = host.Config.make(**cfgd)
+    cfg = host.Config.make(**cfgd, dropout_rate=args.dropout)
     host.seed(42)  # identical N(0, 0.02) init on every rank (then broadcast from rank 0 anyway)
     model = host.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
     trainer = host.Trainer(model, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4)
@@ -187,7 +189,7 @@ def main():
                                    f" patch {cfgd['patch_size']} d={cfgd['embedding_dim']} L={cfgd['num_layers']}"
                                    f" h={cfgd['num_heads']} mlp={cfgd['mlp_hidden_dim']} K={cfgd['num_classes']}"
                                    " (K=1000 assumed: BASELINE.json does not give the class count), one training"
-                                   " step = fwd + softmax-CE + bwd + Adam(L2), dropout 0, random-init weights",
+                                   " step = fwd + softmax-CE + bwd + Adam(L2), dropout " + (f"{args.dropout:g}") + ", random-init weights",
                        "batch_per_gpu": batch, "global_batch": batch * world,
                        "parallelism": f"dp{world}" + (" (bucketed RCCL all-reduce overlapped with backward)" if world > 1 else ""),
                        "patch_mode": "im2col", "params": int(model.n), "final_loss": round(float(loss), 6)},
