@@ -98,6 +98,11 @@ uint64_t vith_num_stages(vith_trainer t);
 int vith_step_backward_stage(vith_trainer t, uint64_t stage);
 int vith_stage_grad_range(vith_trainer t, uint64_t stage, uint64_t *offset, uint64_t *count);
 int vith_step_update(vith_trainer t, float lr, float grad_scale);
+/* Resumable optimizer state: Adam's step count and both moment buffers plus the position of the
+ * dropout stream, written to / read from one file.  With vith_save_weights it continues a
+ * run bit for bit (the reference keeps this state in memory only and cannot resume). */
+int vith_trainer_save_state(vith_trainer t, const char *path);
+int vith_trainer_load_state(vith_trainer t, const char *path);
 int vith_step_result(vith_trainer t, float *loss_host, float *correct_host);
 /* evaluation of one batch in inference mode: loss and number of correct rows */
 int vith_eval_batch(vith_trainer t, const float *x_dev, const float *y_onehot_dev, uint64_t B, float *loss_host,

@@ -410,3 +410,41 @@ def test_vit_b16_full_batch_two_attention_paths_agree_and_step_is_reproducible(H
         e = V.max_relerr(g1[off:off + k], g2[off:off + k], floor=1e-7)
         assert e <= 1e-4, f"grad tensor {i} {shp}: fused vs unfused attention {e:.3e}"
         off += k
+
+
+# ------------------------------------------------------------------ resumable training state
+def test_saved_state_resumes_bit_for_bit(H, tmp_path):
+    """Weights + optimizer/dropout state written after step 3 and loaded into a fresh model continue
+    exactly like the uninterrupted run (dropout on, so the mask stream position matters too).
+    The reference cannot resume at all (Adam's moments live only in memory,
+    src/optimizers/Adam.cpp:22-25); the base .weights format is untouched."""
+    cfgd = dict(V.CONFIGS["C1"], dropout_rate=0.1)
+    cfg = H.Config.make(**cfgd)
+    B = 16
+    xs = [dev(V.rng_normal(100 + s, B, 1, 28, 28)) for s in range(6)]
+    ys = [dev(V.onehot(np.random.default_rng(200 + s).integers(0, 10, B), 10)) for s in range(6)]
+    lr = lambda s: H.cosine_warmup_lr(s, 1, 6, 1e-3)
+    H.seed(5)
+    m = H.Model(cfg)
+    t = H.Trainer(m, weight_decay=1e-4)
+    for s in range(3):
+        t.train_step(xs[s], ys[s], lr(s))
+    w, st = str(tmp_path / "ck.weights"), str(tmp_path / "ck.state")
+    m.save_weights(w)
+    t.save_state(st)
+    for s in range(3, 6):
+        t.train_step(xs[s], ys[s], lr(s))
+    want = m.get_params()
+    # fresh objects (different init, different dropout position), then restore
+    H.seed(77)
+    m2 = H.Model(cfg)
+    t2 = H.Trainer(m2, weight_decay=1e-4)
+    t2.train_step(xs[0], ys[0], 1e-3)  # make sure loading overwrites state that already exists
+    m2.load_weights(w)
+    t2.load_state(st)
+    for s in range(3, 6):
+        t2.train_step(xs[s], ys[s], lr(s))
+    np.testing.assert_array_equal(m2.get_params(), want)
+    # a file that is not a state file is rejected with a message
+    with pytest.raises(Exception, match="formato"):
+        t2.load_state(w)

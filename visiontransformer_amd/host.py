@@ -71,6 +71,8 @@ SIGNATURES = {
     "vith_step_forward": (_int, [_p, _p, _p, _u64, _f]),
     "vith_num_stages": (_u64, [_p]),
     "vith_step_backward_stage": (_int, [_p, _u64]),
+    "vith_trainer_save_state": (_int, [_p, C.c_char_p]),
+    "vith_trainer_load_state": (_int, [_p, C.c_char_p]),
     "vith_stage_grad_range": (_int, [_p, _u64, _pu, _pu]),
     "vith_step_update": (_int, [_p, _f, _f]),
     "vith_step_result": (_int, [_p, _pf, _pf]),
@@ -276,6 +278,12 @@ class Trainer:
 
     def backward_stage(self, s):
         _check(dll().vith_step_backward_stage(self.h, s))
+
+    def save_state(self, path):
+        _check(dll().vith_trainer_save_state(self.h, os.fsencode(path)))
+
+    def load_state(self, path):
+        _check(dll().vith_trainer_load_state(self.h, os.fsencode(path)))
 
     def stage_grad_range(self, s):
         o, c = C.c_uint64(), C.c_uint64()

@@ -46,6 +46,9 @@ void seed(uint64_t s);
 uint64_t next_seed();
 // (seed, offset) pair for the next dropout mask of `count` elements.
 void dropout_stream(size_t count, uint64_t *seed_out, uint64_t *offset_out);
+// Position of the dropout stream (part of a resumable training state).
+void get_dropout_state(uint64_t *seed_out, uint64_t *offset_out);
+void set_dropout_state(uint64_t seed, uint64_t offset);
 
 }  // namespace vit
 

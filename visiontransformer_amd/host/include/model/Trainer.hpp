@@ -6,6 +6,7 @@
 #define TRAINER_HPP
 
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "losses/CrossEntropy.hpp"
@@ -21,6 +22,15 @@ struct TrainerConfig {
   float weight_decay = 0.01f;
   float lr_init = 3e-4f;
   float warmup_frac = 0.1f;
+  // Extensions (empty / 0 = the reference's behaviour).
+  // best_weights_path: after each epoch, save the weights when the test accuracy is a new best and
+  // above the epoch's training accuracy (the policy of cuda_Vit/src/model/Trainer.cu:104-108).
+  std::string best_weights_path;
+  // state_path: write a resumable training state (optimizer moments, step counters, dropout
+  // stream position; see Trainer::saveState) after every epoch, next to the weights in
+  // state_path + ".weights".  start_epoch: first epoch to run when resuming from such a state.
+  std::string state_path;
+  int start_epoch = 0;
 };
 
 class Trainer {
@@ -38,6 +48,14 @@ public:
   std::pair<float, float> evaluate(const Tensor &X_test, const Tensor &y_test);
   void setQuiet(bool q) { quiet = q; }
   Adam &getOptimizer() { return optimizer; }
+  // Everything besides the weights that the next step depends on: Adam's step count and moments,
+  // the schedule position (global step, total steps), the dropout stream position and the number
+  // of epochs completed.  saveState + ModelUtils::save_weights, later load_weights + loadState,
+  // continue a run bit for bit (the reference has no way to resume: src/model/Trainer.cpp keeps
+  // all of this in memory only).  loadState returns the number of completed epochs.
+  void saveState(const std::string &path, int epochs_done = 0);
+  int loadState(const std::string &path);
+  float bestTestAccuracy() const { return best_test_acc; }
   CrossEntropy &getLoss() { return loss_fn; }
 
 private:
@@ -50,6 +68,7 @@ private:
   Logger logger;
   long long global_step = 0;
   long long total_steps = 0;
+  float best_test_acc = 0.0f;
   bool quiet = false;
 };
 

@@ -5,6 +5,7 @@
 #ifndef ADAM_HPP
 #define ADAM_HPP
 
+#include <iosfwd>
 #include <vector>
 
 #include "optimizers/Optimizer.hpp"
@@ -17,8 +18,14 @@ public:
   // gradients are multiplied by this before use (1/world after a sum all-reduce); default 1
   void setGradientScale(float s) { grad_scale = s; }
   long long stepCount() const { return t; }
+  // Resumable state (the reference cannot resume: its optimizer state is never saved): step count
+  // and both moment buffers, written after / read before any number of update() calls.
+  // `parameters` sizes the buffers when the optimizer has not stepped yet.
+  void writeState(std::ostream &out) const;
+  void readState(std::istream &in, const std::vector<Tensor *> &parameters);
 
 private:
+  void allocateMoments(const std::vector<Tensor *> &parameters, bool gradients_flat);
   float beta1, beta2, epsilon, weight_decay;
   long long t;
   std::vector<Tensor> m, v;

@@ -2,6 +2,10 @@
 #include "optimizers/Adam.hpp"
 
 #include <cmath>
+#include <cstdint>
+#include <istream>
+#include <ostream>
+#include <string>
 
 #include "core/Ops.hpp"
 
@@ -23,25 +27,80 @@ bool tiles_one_block(const std::vector<Tensor *> &ts) {
 }
 }  // namespace
 
+void Adam::allocateMoments(const std::vector<Tensor *> &parameters, bool gradients_flat) {
+  flat = gradients_flat && tiles_one_block(parameters);
+  m.clear();
+  v.clear();
+  if (flat) {
+    const size_t n = parameters[0]->storage()->count;
+    m.emplace_back(std::vector<size_t>{n});
+    v.emplace_back(std::vector<size_t>{n});
+  } else {
+    for (const Tensor *p : parameters) {
+      if (!p->isContiguous()) throw std::runtime_error("Adam::update: parámetro no contiguo fuera de un arena.");
+      m.emplace_back(p->getShape());
+      v.emplace_back(p->getShape());
+    }
+  }
+  initialized = true;
+}
+
+// State record: "VITADAM1", i64 step count, u64 number of moment buffers, then per buffer u64 size,
+// f32 m[size], f32 v[size] (native endian, like the .weights format).
+void Adam::writeState(std::ostream &out) const {
+  out.write("VITADAM1", 8);
+  const int64_t steps = t;
+  const uint64_t nbuf = initialized ? m.size() : 0;
+  out.write(reinterpret_cast<const char *>(&steps), sizeof steps);
+  out.write(reinterpret_cast<const char *>(&nbuf), sizeof nbuf);
+  for (uint64_t i = 0; i < nbuf; ++i) {
+    const uint64_t n = m[i].getSize();
+    out.write(reinterpret_cast<const char *>(&n), sizeof n);
+    out.write(reinterpret_cast<const char *>(m[i].data()), (std::streamsize)(n * sizeof(float)));
+    out.write(reinterpret_cast<const char *>(v[i].data()), (std::streamsize)(n * sizeof(float)));
+  }
+  if (!out) throw std::runtime_error("Adam::writeState: error de escritura.");
+}
+
+void Adam::readState(std::istream &in, const std::vector<Tensor *> &parameters) {
+  char magic[8];
+  int64_t steps = 0;
+  uint64_t nbuf = 0;
+  in.read(magic, 8);
+  in.read(reinterpret_cast<char *>(&steps), sizeof steps);
+  in.read(reinterpret_cast<char *>(&nbuf), sizeof nbuf);
+  if (!in || std::string(magic, 8) != "VITADAM1") throw std::runtime_error("Adam::readState: formato desconocido.");
+  t = steps;
+  if (nbuf == 0) {
+    initialized = false;
+    m.clear();
+    v.clear();
+    return;
+  }
+  // a model's parameters and gradients are two arenas of one layout: flat when there is one buffer
+  allocateMoments(parameters, nbuf == 1);
+  if (m.size() != nbuf) throw std::runtime_error("Adam::readState: el estado no corresponde a estos parámetros.");
+  std::vector<float> buf;
+  for (uint64_t i = 0; i < nbuf; ++i) {
+    uint64_t n = 0;
+    in.read(reinterpret_cast<char *>(&n), sizeof n);
+    if (!in || n != m[i].getSize()) throw std::runtime_error("Adam::readState: tamaño de estado incompatible.");
+    buf.resize(n);
+    in.read(reinterpret_cast<char *>(buf.data()), (std::streamsize)(n * sizeof(float)));
+    m[i] = Tensor(m[i].getShape(), buf);
+    in.read(reinterpret_cast<char *>(buf.data()), (std::streamsize)(n * sizeof(float)));
+    v[i] = Tensor(v[i].getShape(), buf);
+    if (!in) throw std::runtime_error("Adam::readState: archivo truncado.");
+  }
+}
+
 void Adam::update(std::vector<Tensor *> &parameters, const std::vector<Tensor *> &gradients) {
   if (parameters.size() != gradients.size())
     throw std::runtime_error("El numero de parametros y gradientes no coincide en Adam::update.");
   if (parameters.empty()) return;
-  if (!initialized) {
-    flat = tiles_one_block(parameters) && tiles_one_block(gradients);
-    if (flat) {
-      const size_t n = parameters[0]->storage()->count;
-      m.emplace_back(std::vector<size_t>{n});
-      v.emplace_back(std::vector<size_t>{n});
-    } else {
-      for (const Tensor *p : parameters) {
-        if (!p->isContiguous()) throw std::runtime_error("Adam::update: parámetro no contiguo fuera de un arena.");
-        m.emplace_back(p->getShape());
-        v.emplace_back(p->getShape());
-      }
-    }
-    initialized = true;
-  }
+  if (!initialized) allocateMoments(parameters, tiles_one_block(gradients));
+  else if (flat && !tiles_one_block(gradients))
+    throw std::runtime_error("Adam::update: estado plano pero gradientes fuera de un arena.");
   t++;
   // bias-correction terms exactly as the reference forms them: float(pow(double(beta), t))
   const float beta1_t = std::pow(beta1, t);

@@ -173,4 +173,14 @@ void dropout_stream(size_t count, uint64_t *seed_out, uint64_t *offset_out) {
   s.dropout_offset += (count + 3) / 4;
 }
 
+void get_dropout_state(uint64_t *seed_out, uint64_t *offset_out) {
+  *seed_out = S().dropout_seed;
+  *offset_out = S().dropout_offset;
+}
+
+void set_dropout_state(uint64_t seed, uint64_t offset) {
+  S().dropout_seed = seed;
+  S().dropout_offset = offset;
+}
+
 }  // namespace vit

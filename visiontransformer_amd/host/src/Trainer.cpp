@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <fstream>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
@@ -12,6 +13,7 @@
 #include <sstream>
 
 #include "optimizers/Scheduler.hpp"
+#include "utils/ModelUtils.hpp"
 
 Trainer::Trainer(VisionTransformer &model, const TrainerConfig &train_config, const std::vector<float> &class_weights)
     : model(model), optimizer(train_config.learning_rate, 0.9f, 0.999f, 1e-8f, train_config.weight_decay), loss_fn(),
@@ -39,7 +41,7 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
   const Tensor &X_test = test_data.first, &y_test = test_data.second;
   const size_t batches_per_epoch = (X_train.getShape()[0] + config.batch_size - 1) / config.batch_size;
   total_steps = (long long)batches_per_epoch * config.epochs;
-  for (int epoch = 0; epoch < config.epochs; ++epoch) {
+  for (int epoch = config.start_epoch; epoch < config.epochs; ++epoch) {
     const auto start = std::chrono::high_resolution_clock::now();
     auto [train_loss, train_acc] = train_epoch(X_train, y_train, epoch);
     if (!quiet) std::cout << "\r" << std::string(80, ' ') << "\r";
@@ -47,6 +49,14 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
     const auto ms_total =
         std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
     logger.log_epoch(epoch, config.epochs, train_loss, train_acc, test_loss, test_acc);
+    if (!config.best_weights_path.empty() && test_acc > best_test_acc && test_acc > train_acc) {
+      ModelUtils::save_weights(model, config.best_weights_path);
+      best_test_acc = test_acc;
+    }
+    if (!config.state_path.empty()) {
+      ModelUtils::save_weights(model, config.state_path + ".weights");
+      saveState(config.state_path, epoch + 1);
+    }
     std::ostringstream t;
     t << std::setfill('0') << "[" << std::setw(2) << ms_total / 3600000 << ":" << std::setw(2)
       << (ms_total % 3600000) / 60000 << ":" << std::setw(2) << (ms_total % 60000) / 1000 << "." << std::setw(3)
@@ -56,6 +66,47 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
               << "\033[0m | \033[1;32mTest Loss: " << test_loss << " | Test Acc: " << test_acc << "\033[0m \033[1;35m"
               << t.str() << "\033[0m" << std::endl;
   }
+}
+
+// State file: "VITTRAIN1", i64 global step, i64 total steps, i64 epochs done, f32 best test
+// accuracy, u64 dropout seed, u64 dropout offset, then Adam's record (Adam::writeState).
+void Trainer::saveState(const std::string &path, int epochs_done) {
+  std::ofstream out(path, std::ios::binary);
+  if (!out) throw std::runtime_error("No se pudo abrir el archivo de estado para escritura: " + path);
+  const int64_t gs = global_step, ts = total_steps, ep = epochs_done;
+  uint64_t dseed = 0, doff = 0;
+  vit::get_dropout_state(&dseed, &doff);
+  out.write("VITTRAIN1", 9);
+  out.write(reinterpret_cast<const char *>(&gs), sizeof gs);
+  out.write(reinterpret_cast<const char *>(&ts), sizeof ts);
+  out.write(reinterpret_cast<const char *>(&ep), sizeof ep);
+  out.write(reinterpret_cast<const char *>(&best_test_acc), sizeof best_test_acc);
+  out.write(reinterpret_cast<const char *>(&dseed), sizeof dseed);
+  out.write(reinterpret_cast<const char *>(&doff), sizeof doff);
+  optimizer.writeState(out);
+  if (!out) throw std::runtime_error("Error de escritura en el archivo de estado: " + path);
+}
+
+int Trainer::loadState(const std::string &path) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw std::runtime_error("No se pudo abrir el archivo de estado para lectura: " + path);
+  char magic[9];
+  int64_t gs = 0, ts = 0, ep = 0;
+  uint64_t dseed = 0, doff = 0;
+  in.read(magic, 9);
+  in.read(reinterpret_cast<char *>(&gs), sizeof gs);
+  in.read(reinterpret_cast<char *>(&ts), sizeof ts);
+  in.read(reinterpret_cast<char *>(&ep), sizeof ep);
+  in.read(reinterpret_cast<char *>(&best_test_acc), sizeof best_test_acc);
+  in.read(reinterpret_cast<char *>(&dseed), sizeof dseed);
+  in.read(reinterpret_cast<char *>(&doff), sizeof doff);
+  if (!in || std::string(magic, 9) != "VITTRAIN1")
+    throw std::runtime_error("Archivo de estado con formato desconocido: " + path);
+  global_step = gs;
+  total_steps = ts;
+  vit::set_dropout_state(dseed, doff);
+  optimizer.readState(in, model.getParameters());
+  return (int)ep;
 }
 
 std::pair<float, float> Trainer::train_epoch(const Tensor &X_train, const Tensor &y_train, int epoch) {

@@ -11,6 +11,8 @@
 #include "core/Device.hpp"
 #include "core/Ops.hpp"
 #include "model/Trainer.hpp"
+#include <fstream>
+
 #include "optimizers/Scheduler.hpp"
 #include "utils/ModelUtils.hpp"
 
@@ -245,6 +247,35 @@ int vith_step_update(vith_trainer t, float lr, float grad_scale) {
     s->adam.setLearningRate(lr);
     s->adam.setGradientScale(grad_scale);
     s->adam.update(p, g);
+  });
+}
+int vith_trainer_save_state(vith_trainer t, const char *path) {
+  return guard([&] {
+    if (!path) throw std::invalid_argument("vith_trainer_save_state: null path");
+    std::ofstream out(path, std::ios::binary);
+    if (!out) throw std::runtime_error(std::string("No se pudo abrir el archivo de estado para escritura: ") + path);
+    uint64_t dseed = 0, doff = 0;
+    vit::get_dropout_state(&dseed, &doff);
+    out.write("VITSTEP1", 8);
+    out.write(reinterpret_cast<const char *>(&dseed), sizeof dseed);
+    out.write(reinterpret_cast<const char *>(&doff), sizeof doff);
+    T(t)->adam.writeState(out);
+  });
+}
+int vith_trainer_load_state(vith_trainer t, const char *path) {
+  return guard([&] {
+    if (!path) throw std::invalid_argument("vith_trainer_load_state: null path");
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error(std::string("No se pudo abrir el archivo de estado para lectura: ") + path);
+    char magic[8];
+    uint64_t dseed = 0, doff = 0;
+    in.read(magic, 8);
+    in.read(reinterpret_cast<char *>(&dseed), sizeof dseed);
+    in.read(reinterpret_cast<char *>(&doff), sizeof doff);
+    if (!in || std::string(magic, 8) != "VITSTEP1")
+      throw std::runtime_error(std::string("Archivo de estado con formato desconocido: ") + path);
+    vit::set_dropout_state(dseed, doff);
+    T(t)->adam.readState(in, T(t)->model->vit.getParameters());
   });
 }
 int vith_step_result(vith_trainer t, float *loss, float *correct) {
