@@ -448,3 +448,64 @@ def test_saved_state_resumes_bit_for_bit(H, tmp_path):
     # a file that is not a state file is rejected with a message
     with pytest.raises(Exception, match="formato"):
         t2.load_state(w)
+
+
+# ------------------------------------------------- checkpoints written by the reference's CUDA tree
+def read_weights_tensors(path):
+    """[(shape, float32 array)] of a .weights file: u64 rank, u64 dims[rank], f32 data per tensor."""
+    raw = open(path, "rb").read()
+    out, off = [], 0
+    while off < len(raw):
+        rank = int(np.frombuffer(raw, np.uint64, 1, off)[0]); off += 8
+        shape = tuple(int(v) for v in np.frombuffer(raw, np.uint64, rank, off)); off += 8 * rank
+        n = int(np.prod(shape))
+        out.append((shape, np.frombuffer(raw, np.float32, n, off).copy())); off += 4 * n
+    return out
+
+
+def test_cuda_tree_checkpoint_loads_with_conv_patch_projection(H, tmp_path):
+    """tests/golden/cuda_vit_blood_rgb.{json,weights} are the data files cuda_Vit/models/
+    vit_blood_rgb_test_best.* of the reference, copied verbatim (patch projection stored as a
+    Conv2d weight {96,3,14,14} + bias {1,96,1,1}).  The CUDA tree cannot be built here, so the
+    expected logits come from a float64 restatement of that model written with a real strided
+    convolution (parity of this loader against the CUDA tree itself: unpinned; every other layer is
+    pinned by the CPU-reference goldens above)."""
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cuda_vit_blood_rgb")
+    cfg = H.load_config(base + ".json")
+    assert (cfg.in_channels, cfg.patch_size, cfg.embedding_dim, cfg.num_layers) == (3, 14, 96, 8)
+    m = H.Model(cfg)  # built in the reference patch mode: the loader must switch it
+    m.load_weights(base + ".weights")
+    ts = read_weights_tensors(base + ".weights")
+    assert ts[0][0] == (96, 3, 14, 14) and ts[1][0] == (1, 96, 1, 1) and len(ts) == 4 + 16 * 8 + 4
+    x = V.rng_normal(31, 5, 3, 28, 28)
+    got = host_np(m.forward(dev(x), training=False))
+
+    t64 = [torch.tensor(a.reshape(s), dtype=torch.float64) for s, a in ts]
+    xt = torch.tensor(x, dtype=torch.float64)
+    B, D, nh, L = 5, 96, cfg.num_heads, cfg.num_layers
+    conv = torch.nn.functional.conv2d(xt, t64[0], t64[1].reshape(-1), stride=14)  # {B, D, 2, 2}
+    h = torch.cat([t64[2].expand(B, 1, D), conv.reshape(B, D, -1).transpose(1, 2)], 1) + t64[3]
+    N = h.shape[1]
+    gelu = lambda v: 0.5 * v * (1 + torch.tanh(0.7978845608028654 * (v + 0.044715 * v ** 3)))
+    ln = lambda v, g_, b_: (v - v.mean(-1, keepdim=True)) / torch.sqrt(v.var(-1, unbiased=False, keepdim=True) + 1e-5) * g_ + b_
+    for l in range(L):
+        q = t64[4 + 16 * l:4 + 16 * (l + 1)]
+        a = ln(h, q[0], q[1])
+        sp = lambda t_: t_.reshape(B, N, nh, D // nh).transpose(1, 2)
+        qq, kk, vv = sp(a @ q[2] + q[3]), sp(a @ q[4] + q[5]), sp(a @ q[6] + q[7])
+        att = torch.softmax(qq @ kk.transpose(-1, -2) / np.sqrt(D // nh), -1) @ vv
+        h = h + att.transpose(1, 2).reshape(B, N, D) @ q[8] + q[9]
+        f = ln(h, q[10], q[11])
+        h = h + gelu(f @ q[12] + q[13]) @ q[14] + q[15]
+    tail = t64[4 + 16 * L:]
+    want = (ln(h, tail[0], tail[1])[:, 0] @ tail[2] + tail[3]).numpy()
+    close(got, want, ACT_TOL, "logits of the CUDA-tree checkpoint")
+    np.testing.assert_array_equal(got.argmax(1), want.argmax(1))
+    # saving writes this tree's layout ({C*P*P, D}); a model that reloads it needs im2col patches
+    out = str(tmp_path / "resaved.weights")
+    m.save_weights(out)
+    assert read_weights_tensors(out)[0][0] == (3 * 14 * 14, 96)
+    from visiontransformer_amd import vitk
+    m2 = H.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
+    m2.load_weights(out)
+    np.testing.assert_array_equal(host_np(m2.forward(dev(x), training=False)), got)

@@ -14,6 +14,10 @@
 namespace ModelUtils {
 
 void save_weights(const VisionTransformer &model, const std::string &filePath);
+// Also reads checkpoints of the reference's CUDA tree (cuda_Vit/models/*.weights): their patch
+// projection is a Conv2d weight {D, C, P, P} + bias {1, D, 1, 1}; it is transposed into this
+// model's {C*P*P, D} matrix and the model is switched to im2col patch extraction, which is what
+// that convolution computes.
 void load_weights(VisionTransformer &model, const std::string &filePath);
 void save_config(const ViTConfig &config, const std::string &filePath);
 ViTConfig load_config(const std::string &filePath);

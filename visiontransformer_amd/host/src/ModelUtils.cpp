@@ -110,13 +110,33 @@ void load_weights(VisionTransformer &model, const std::string &filePath) {
   auto params = model.getParameters();
   if (g_verbose)
     std::cout << "Cargando " << params.size() << " tensores de parámetros desde " << filePath << "..." << std::endl;
-  for (Tensor *t : params) {
+  for (size_t index = 0; index < params.size(); ++index) {
+    Tensor *t = params[index];
     size_t rank = 0;
     in.read(reinterpret_cast<char *>(&rank), sizeof(size_t));
     if (!in || rank > 8) throw std::runtime_error("Error de lectura: fin de archivo inesperado o datos corruptos.");
     std::vector<size_t> shape(rank);
     in.read(reinterpret_cast<char *>(shape.data()), rank * sizeof(size_t));
     if (!in) throw std::runtime_error("Error de lectura: fin de archivo inesperado o datos corruptos.");
+    // Checkpoints written by the reference's CUDA tree store the patch projection as a Conv2d:
+    // weight {D, C, P, P}, bias {1, D, 1, 1} (cuda_Vit/src/layers/PatchEmbedding.cu:36,
+    // cuda_Vit/src/layers/Conv2d.cu), applied to true (channel, row, column) patches.  That is
+    // this model's {C*P*P, D} projection transposed, with im2col patch extraction.
+    if (index == 0 && rank == 4 && t->getShape().size() == 2 && shape[0] == t->getShape()[1] &&
+        shape[1] * shape[2] * shape[3] == t->getShape()[0]) {
+      const size_t D = shape[0], pd = t->getShape()[0];
+      std::vector<float> conv(D * pd), w(pd * D);
+      in.read(reinterpret_cast<char *>(conv.data()), conv.size() * sizeof(float));
+      if (static_cast<size_t>(in.gcount()) != conv.size() * sizeof(float))
+        throw std::runtime_error("Error de lectura: fin de archivo inesperado o datos corruptos.");
+      for (size_t d = 0; d < D; ++d)
+        for (size_t j = 0; j < pd; ++j) w[j * D + d] = conv[d * pd + j];
+      t->copyFrom(Tensor(t->getShape(), w));
+      model.getEmbeddings().getPatcher().setPatchMode(VITK_PATCH_IM2COL);
+      continue;
+    }
+    if (index == 1 && rank == 4 && shape[0] == 1 && shape[2] == 1 && shape[3] == 1 && shape[1] == t->getSize())
+      shape = t->getShape();  // {1, D, 1, 1}: same D floats
     if (t->getShape() != shape)
       throw std::runtime_error("Incompatibilidad de formas al cargar pesos. Esperado: " + t->shapeToString() +
                                ", encontrado en archivo: " + Tensor(shape).shapeToString());
