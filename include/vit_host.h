@@ -77,6 +77,17 @@ int vith_backward(vith_model m, const float *dlogits_dev, uint64_t B, float *dac
 /* top-1: first index of the row maximum of softmax(logits) (app/test.cpp:92-112) */
 int vith_predict(vith_model m, const float *x_dev, uint64_t B, int32_t *pred_dev);
 
+/* ---- whole training run: Trainer::train (src/model/Trainer.cpp:60-236) on host data -----------
+ * x is [n][C][H][W], y one-hot [n][K] (x_test / y_test likewise).  Per epoch: sample order =
+ * iota shuffled by mt19937(epoch), batches of batch_size (last one ragged), cosine/warm-up
+ * schedule over epochs * batches steps, Adam(L2), then evaluation on the test set in batches.
+ * The data set is uploaded once and batches are gathered on the device.  history (may be NULL)
+ * receives {train loss, train accuracy, test loss, test accuracy} per epoch.  Writes the
+ * reference's vit_results.csv log into the current directory.  No augmentation is applied. */
+int vith_fit(vith_model m, const float *x, const float *y_onehot, uint64_t n, const float *x_test,
+             const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
+             float weight_decay, float warmup_frac, float *history);
+
 /* ---- trainer: the per-batch body of Trainer::train_epoch (src/model/Trainer.cpp:201-227) ---- */
 vith_trainer vith_trainer_create(vith_model m, float beta1, float beta2, float eps, float weight_decay,
                                  const float *class_weights_host, uint64_t n_weights);

@@ -195,6 +195,12 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
                   int32_t dk_mode, float *dq, float *dk, float *dv, int64_t ld_dqkv, float *workspace,
                   size_t workspace_bytes, vitk_stream_t stream);
 
+/* ---- batch assembly: dst[r][:] = src[index[r]][:]  (the per-batch gather of shuffled samples,
+ * src/model/Trainer.cpp:163-199, done on the device from a dataset that stays resident in HBM).
+ * index is a device array of `rows` int32 values in [0, src_rows). */
+int vitk_gather_rows_f32(const float *src, int64_t src_rows, const int32_t *index, int64_t rows, int64_t row_len,
+                         float *dst, vitk_stream_t stream);
+
 /* ---- patch extraction (src/layers/PatchEmbedding.cpp:31-52) -----------------------------------
  * img is [B][C][HW][HW]; patches is [B*Np][P*P*C], Np = (HW/P)^2.
  * VITK_PATCH_REFERENCE: what the reference CPU path does -- patch (ph,pw) is the P*P*C CONTIGUOUS

@@ -443,6 +443,15 @@ def test_gemm_column_sums_need_untransposed_b(K):
         K.gemm(a, a, c, 8, 8, 8, trans_b=True, colsum_b=s)
 
 
+def test_gather_rows_assembles_a_shuffled_batch(K):
+    src = V.rng_normal(3, 50, 37)
+    idx = np.random.default_rng(4).permutation(50)[:21].astype(np.int32)
+    out = empty(21, 37)
+    K.call("vitk_gather_rows_f32", dev(src), 50, dev(idx), 21, 37, out, K.stream())
+    np.testing.assert_array_equal(host(out), src[idx])
+    K.call("vitk_gather_rows_f32", dev(src), 50, dev(idx), 0, 37, out, K.stream())  # empty batch: no-op
+
+
 # ---------------------------------------- fused attention (vitk_sdpa_fwd / vitk_sdpa_bwd)
 def sdpa_numpy(q, k, v, do, scale):
     """float64 attention per (batch, head): q, k, v, do are [B][H][N][dh]."""

@@ -509,3 +509,64 @@ def test_cuda_tree_checkpoint_loads_with_conv_patch_projection(H, tmp_path):
     m2 = H.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
     m2.load_weights(out)
     np.testing.assert_array_equal(host_np(m2.forward(dev(x), training=False)), got)
+
+
+# ------------------------------------------------------------------ the whole Trainer::train loop
+def test_fit_reproduces_the_reference_epoch_loop(H, tmp_path, monkeypatch):
+    """Trainer::train through the C-ABI (data set resident on the device, batches gathered there)
+    against the same loop spelled out in Python around the CPU oracle: per-epoch mt19937(epoch)
+    shuffle, ragged last batch, cosine/warm-up schedule over all steps, Adam(L2), batched
+    evaluation (src/model/Trainer.cpp:60-271, without the reference's random augmentation)."""
+    monkeypatch.chdir(tmp_path)  # the trainer writes the reference's vit_results.csv log here
+    O = V.oracle()
+    cfgd = V.TINY
+    ocfg = V.Cfg.make(**cfgd)
+    n, nt, E, BS, K = 70, 23, 2, 32, ocfg.num_classes
+    x = V.rng_normal(41, n, 1, 28, 28)
+    y = V.onehot(np.random.default_rng(42).integers(0, K, n), K)
+    xt = V.rng_normal(43, nt, 1, 28, 28)
+    yt = V.onehot(np.random.default_rng(44).integers(0, K, nt), K)
+    prm = V.init_params(ocfg, 45)
+    lr_init, wd, wf = 1e-3, 1e-4, 0.1
+
+    m = H.Model(hcfg(H, cfgd))
+    m.set_params(prm)
+    hist = m.fit(x, y, xt, yt, E, BS, lr_init, wd, wf)
+
+    s = O.vo_session_create(ocfg, 0.9, 0.999, 1e-8, wd)
+    O.vo_session_set_params(s, prm)
+    nb = (n + BS - 1) // BS
+    total, step, want = nb * E, 0, []
+    for epoch in range(E):
+        order = H.epoch_order(n, epoch)
+        tl = ta = 0.0
+        for b in range(nb):
+            idx = order[b * BS:(b + 1) * BS]
+            xb, yb = np.ascontiguousarray(x[idx]), np.ascontiguousarray(y[idx])
+            logits = V.f32(len(idx), K)
+            lr = H.cosine_warmup_lr(step, int(wf * total), total, lr_init)
+            tl += O.vo_session_train_step(s, xb, yb, len(idx), lr, logits, None)
+            ta += float((logits.argmax(1) == yb.argmax(1)).mean())
+            step += 1
+        p = V.f32(len(prm))
+        O.vo_session_get_params(s, p)
+        el = ea = 0.0
+        nbt = (nt + BS - 1) // BS
+        for b in range(nbt):
+            xb, yb = np.ascontiguousarray(xt[b * BS:(b + 1) * BS]), yt[b * BS:(b + 1) * BS]
+            logits = V.f32(len(xb), K)
+            O.vo_forward(ocfg, p, xb, len(xb), logits, None)
+            z = logits.astype(np.float64)
+            pr = np.exp(z - z.max(1, keepdims=True))
+            pr /= pr.sum(1, keepdims=True)
+            el += float(-np.log((pr * yb).sum(1) + 1e-12).mean())
+            ea += float((logits.argmax(1) == yb.argmax(1)).mean())
+        want.append([tl / nb, ta / nb, el / nbt, ea / nbt])
+    want = np.array(want)
+    assert np.abs(hist[:, [0, 2]] - want[:, [0, 2]]).max() <= 1e-4 * np.abs(want[:, [0, 2]]).max(), (hist, want)
+    np.testing.assert_allclose(hist[:, [1, 3]], want[:, [1, 3]], atol=1e-6)
+    p = V.f32(len(prm))
+    O.vo_session_get_params(s, p)
+    V.check_digest(m.get_params(), V.param_shapes(ocfg), *V.tensor_digest(p, V.param_shapes(ocfg)), 5e-5,
+                   "parameters after two epochs")
+    assert os.path.exists("vit_results.csv")

@@ -28,6 +28,17 @@ __global__ void patch_gather_kernel(const float *__restrict__ img, int B, int C,
   }
 }
 
+// dst[r][:] = src[index[r]][:]
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ index, long long rows,
+                                   long long row_len, float *__restrict__ dst) {
+  const long long total = rows * row_len;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / row_len, c = i % row_len;
+    dst[i] = src[(long long)index[r] * row_len + c];
+  }
+}
+
 __global__ void embed_assemble_kernel(const float *__restrict__ proj, const float *__restrict__ cls,
                                       const float *__restrict__ pos, int B, int Np, int D, float *__restrict__ out) {
   const int N = Np + 1;
@@ -125,6 +136,16 @@ int vitk_embed_split_bwd(const float *dy, int32_t B, int32_t Np, int32_t D, floa
   hipLaunchKernelGGL(embed_split_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream), dy, B,
                      Np, D, dproj);
   return vitk::check_launch("vitk_embed_split_bwd");
+}
+
+int vitk_gather_rows_f32(const float *src, int64_t src_rows, const int32_t *index, int64_t rows, int64_t row_len,
+                         float *dst, vitk_stream_t stream) {
+  VITK_REQUIRE(rows >= 0 && row_len >= 0 && src_rows >= 0, "vitk_gather_rows_f32: bad shape");
+  if (rows == 0 || row_len == 0) return 0;
+  VITK_REQUIRE(src && index && dst && src_rows > 0, "vitk_gather_rows_f32: null pointer or empty source");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(vitk::grid_for(rows * row_len, TPB)), dim3(TPB), 0,
+                     vitk::as_stream(stream), src, index, (long long)rows, (long long)row_len, dst);
+  return vitk::check_launch("vitk_gather_rows_f32");
 }
 
 int vitk_cls_gather(const float *x, int32_t B, int32_t N, int32_t D, float *cls_rows, vitk_stream_t stream) {

@@ -71,6 +71,7 @@ SIGNATURES = {
     "vith_step_forward": (_int, [_p, _p, _p, _u64, _f]),
     "vith_num_stages": (_u64, [_p]),
     "vith_step_backward_stage": (_int, [_p, _u64]),
+    "vith_fit": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float, _p]),
     "vith_trainer_save_state": (_int, [_p, C.c_char_p]),
     "vith_trainer_load_state": (_int, [_p, C.c_char_p]),
     "vith_stage_grad_range": (_int, [_p, _u64, _pu, _pu]),
@@ -205,6 +206,14 @@ class Model:
 
     def grads_device(self):
         return dll().vith_grads_device(self.h)
+
+    def fit(self, x, y, x_test, y_test, epochs, batch_size, lr_init=3e-4, weight_decay=1e-4, warmup_frac=0.1):
+        """Trainer::train on host numpy arrays; returns [epochs][4] = train loss/acc, test loss/acc."""
+        x, y, x_test, y_test = (np.ascontiguousarray(a, np.float32) for a in (x, y, x_test, y_test))
+        hist = np.zeros((epochs, 4), np.float32)
+        _check(dll().vith_fit(self.h, x.ctypes.data, y.ctypes.data, x.shape[0], x_test.ctypes.data, y_test.ctypes.data,
+                              x_test.shape[0], epochs, batch_size, lr_init, weight_decay, warmup_frac, hist.ctypes.data))
+        return hist
 
     def save_weights(self, path):
         _check(dll().vith_save_weights(self.h, os.fsencode(path)))

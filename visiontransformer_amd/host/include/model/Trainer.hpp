@@ -5,6 +5,7 @@
 #ifndef TRAINER_HPP
 #define TRAINER_HPP
 
+#include <array>
 #include <memory>
 #include <string>
 #include <vector>
@@ -56,6 +57,8 @@ public:
   void saveState(const std::string &path, int epochs_done = 0);
   int loadState(const std::string &path);
   float bestTestAccuracy() const { return best_test_acc; }
+  // {train loss, train accuracy, test loss, test accuracy} of every epoch train() has run
+  const std::vector<std::array<float, 4>> &history() const { return epoch_history; }
   CrossEntropy &getLoss() { return loss_fn; }
 
 private:
@@ -69,6 +72,7 @@ private:
   long long global_step = 0;
   long long total_steps = 0;
   float best_test_acc = 0.0f;
+  std::vector<std::array<float, 4>> epoch_history;
   bool quiet = false;
 };
 

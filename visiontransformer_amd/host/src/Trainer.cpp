@@ -12,6 +12,7 @@
 #include <random>
 #include <sstream>
 
+#include "core/Ops.hpp"
 #include "optimizers/Scheduler.hpp"
 #include "utils/ModelUtils.hpp"
 
@@ -49,6 +50,7 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
     const auto ms_total =
         std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
     logger.log_epoch(epoch, config.epochs, train_loss, train_acc, test_loss, test_acc);
+    epoch_history.push_back({train_loss, train_acc, test_loss, test_acc});
     if (!config.best_weights_path.empty() && test_acc > best_test_acc && test_acc > train_acc) {
       ModelUtils::save_weights(model, config.best_weights_path);
       best_test_acc = test_acc;
@@ -61,7 +63,8 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
     t << std::setfill('0') << "[" << std::setw(2) << ms_total / 3600000 << ":" << std::setw(2)
       << (ms_total % 3600000) / 60000 << ":" << std::setw(2) << (ms_total % 60000) / 1000 << "." << std::setw(3)
       << ms_total % 1000 << "]";
-    std::cout << "\033[1m--- Epoch " << (epoch + 1) << "/" << config.epochs << "\033[0m | \033[1;34mTrain Loss: "
+    if (!quiet)
+      std::cout << "\033[1m--- Epoch " << (epoch + 1) << "/" << config.epochs << "\033[0m | \033[1;34mTrain Loss: "
               << std::fixed << std::setprecision(4) << train_loss << " | Train Acc: " << train_acc
               << "\033[0m | \033[1;32mTest Loss: " << test_loss << " | Test Acc: " << test_acc << "\033[0m \033[1;35m"
               << t.str() << "\033[0m" << std::endl;
@@ -119,21 +122,27 @@ std::pair<float, float> Trainer::train_epoch(const Tensor &X_train, const Tensor
   std::iota(indices.begin(), indices.end(), 0);
   std::mt19937 rng(static_cast<uint32_t>(epoch));
   std::shuffle(indices.begin(), indices.end(), rng);
+  // The data set stays resident in HBM (uploaded once; 288 GB hold every data set the reference
+  // trains on many times over) and each batch is gathered on the device: no per-step host copy,
+  // no per-step upload.  The epoch's sample order goes up as one int32 array.
   Tensor Xs = X_train.dense(), ys = y_train.dense();
-  const float *xsrc = Xs.data(), *ysrc = ys.data();
-  std::vector<float> xb, yb;
+  const float *xsrc = Xs.deviceData(), *ysrc = ys.deviceData();
+  std::vector<int32_t> order32(indices.begin(), indices.end());
+  Tensor order_dev = Tensor::deviceEmpty({n});  // n int32 values in a 4-byte-per-element block
+  vit::copy_to_device(order_dev.deviceDataOverwrite(), reinterpret_cast<const float *>(order32.data()), n);
+  const int32_t *order = reinterpret_cast<const int32_t *>(order_dev.deviceData());
   for (size_t i = 0; i < num_batches; ++i) {
     const size_t first = i * config.batch_size;
     const size_t count = std::min(config.batch_size, n - first);
     if (count == 0) continue;
-    xb.resize(count * sample);
-    yb.resize(count * K);
-    for (size_t j = 0; j < count; ++j) {
-      const size_t src = indices[first + j];
-      std::memcpy(xb.data() + j * sample, xsrc + src * sample, sample * sizeof(float));
-      std::memcpy(yb.data() + j * K, ysrc + src * K, K * sizeof(float));
-    }
-    Tensor X_batch({count, shape[1], shape[2], shape[3]}, xb), y_batch({count, K}, yb);
+    Tensor X_batch = Tensor::deviceEmpty({count, shape[1], shape[2], shape[3]});
+    Tensor y_batch = Tensor::deviceEmpty({count, K});
+    vit::check(vitk_gather_rows_f32(xsrc, (int64_t)n, order + first, (int64_t)count, (int64_t)sample,
+                                    X_batch.deviceDataOverwrite(), vit::stream()),
+               "vitk_gather_rows_f32");
+    vit::check(vitk_gather_rows_f32(ysrc, (int64_t)n, order + first, (int64_t)count, (int64_t)K,
+                                    y_batch.deviceDataOverwrite(), vit::stream()),
+               "vitk_gather_rows_f32");
     const long long warmup_steps = (long long)(config.warmup_frac * total_steps);
     const float lr_now = cosine_warmup_lr(global_step, warmup_steps, total_steps, config.lr_init);
     float acc = 0.0f;

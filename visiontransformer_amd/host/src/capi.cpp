@@ -249,6 +249,33 @@ int vith_step_update(vith_trainer t, float lr, float grad_scale) {
     s->adam.update(p, g);
   });
 }
+int vith_fit(vith_model m, const float *x, const float *y, uint64_t n, const float *x_test, const float *y_test,
+             uint64_t n_test, int epochs, uint64_t batch_size, float lr_init, float weight_decay, float warmup_frac,
+             float *history) {
+  return guard([&] {
+    VisionTransformer &v = M(m)->vit;
+    const ViTConfig &c = v.getConfig();
+    const size_t sample = c.in_channels * c.image_size * c.image_size, K = c.num_classes;
+    auto wrap = [&](const float *px, const float *py, uint64_t rows) {
+      return std::make_pair(
+          Tensor({(size_t)rows, c.in_channels, c.image_size, c.image_size}, std::vector<float>(px, px + rows * sample)),
+          Tensor({(size_t)rows, K}, std::vector<float>(py, py + rows * K)));
+    };
+    TrainerConfig tc;
+    tc.epochs = epochs;
+    tc.batch_size = (size_t)batch_size;
+    tc.lr_init = lr_init;
+    tc.learning_rate = lr_init;
+    tc.weight_decay = weight_decay;
+    tc.warmup_frac = warmup_frac;
+    Trainer trainer(v, tc);
+    trainer.setQuiet(true);
+    trainer.train(wrap(x, y, n), wrap(x_test, y_test, n_test));
+    const auto &h = trainer.history();
+    for (size_t e = 0; e < h.size() && history; ++e)
+      for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
+  });
+}
 int vith_trainer_save_state(vith_trainer t, const char *path) {
   return guard([&] {
     if (!path) throw std::invalid_argument("vith_trainer_save_state: null path");
