@@ -75,6 +75,7 @@ def batches():
 
 def worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # container hostnames may not resolve
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = OracleEngine(seed=100 + rank)  # different init per rank: the broadcast must fix that
     ddp = dp.DataParallel(eng, bucket_bytes=16 << 10)  # small buckets => several collectives per step
