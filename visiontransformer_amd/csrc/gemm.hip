@@ -701,11 +701,10 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   // remainder after the last full round (N = 768: 394 x 6 tiles = 3 rounds + 60), those few 128-wide
   // tiles would each run alone on a CU while most CUs idle.  Cut the trailing tile rows off and run
   // them as a second launch, which make_plan covers with four times as many 64-wide tiles.
-  static const bool tail_split = getenv("VITK_GEMM_NO_TAIL_SPLIT") == nullptr;
-  if (tail_split && a->reserved == 0 && pl.tile == 128 && pl.split_k == 1 && pl.batch == 1 &&
+  if (a->reserved == 0 && pl.tile == 128 && pl.split_k == 1 && pl.batch == 1 &&
       a->colsum_b == nullptr) {
     const int slots = 256 * kBlocksPerCU;
-    static const int tail_max = getenv("VITK_GEMM_TAIL_MAX") ? atoi(getenv("VITK_GEMM_TAIL_MAX")) : 128;
+    constexpr int tail_max = 128;  // larger remainders already spread over most CUs (measured: no gain)
     const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
     const int head_rows = (int)(tiles / slots * slots / pl.tiles_n);  // tile rows inside the full rounds
     const int tail_rows = pl.tiles_m - head_rows;
@@ -746,8 +745,8 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   p.colsum = a->colsum_b;
   p.colsum_ws = pl.split_k > 1 && a->colsum_b ? a->workspace + (size_t)pl.split_k * pl.batch * a->M * a->N : nullptr;
   {  // column strips of at most 8 tiles, as even as possible
-    static const int strip_env = getenv("VITK_GEMM_STRIP") ? atoi(getenv("VITK_GEMM_STRIP")) : 8;
-    const int nstrips = (pl.tiles_n + strip_env - 1) / strip_env;
+    constexpr int kMaxStrip = 8;
+    const int nstrips = (pl.tiles_n + kMaxStrip - 1) / kMaxStrip;
     p.strip = (pl.tiles_n + nstrips - 1) / nstrips;
   }
   p.vec_a = strides_vec_ok(a->A, a->lda, a->stride_a_outer, a->stride_a_inner);
