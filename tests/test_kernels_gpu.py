@@ -443,6 +443,23 @@ def test_gemm_column_sums_need_untransposed_b(K):
         K.gemm(a, a, c, 8, 8, 8, trans_b=True, colsum_b=s)
 
 
+@pytest.mark.parametrize("ta", [0, 1])
+def test_gemm_tail_round_split_keeps_every_epilogue_operand_aligned(K, ta):
+    """773 x 1 tiles of 128 = one full round of 768 workgroups + 5: the library runs the last 5 tile
+    rows as a second launch.  Bias, pre-activation output, GELU and residual must land on the
+    right rows of both parts."""
+    M, N, Kd = 773 * 128, 128, 32
+    a = V.rng_normal(7, *((Kd, M) if ta else (M, Kd)))
+    b, bias, res = V.rng_normal(8, Kd, N), V.rng_normal(9, N), V.rng_normal(10, M, N)
+    c, aux = empty(M, N), empty(M, N)
+    K.gemm(dev(a), dev(b), c, M, N, Kd, trans_a=bool(ta), bias=dev(bias), act=K.ACT_GELU_FWD, aux=aux,
+           residual=dev(res))
+    pre = ref_gemm(a, b, ta, 0) + bias
+    close(host(aux), pre, 1e-5)
+    gelu = 0.5 * pre * (1.0 + np.tanh(0.7978845608028654 * (pre + 0.044715 * pre ** 3)))
+    close(host(c), gelu + res, 1e-5)
+
+
 def test_gather_rows_assembles_a_shuffled_batch(K):
     src = V.rng_normal(3, 50, 37)
     idx = np.random.default_rng(4).permutation(50)[:21].astype(np.int32)
