@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise RCCL and issue the bucket all-reduces even with one rank (rehearsal of the "
+                         "multi-GPU code path on a one-GPU box)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="dropout rate (0 = the headline/parity configuration; 0.1 adds the device RNG cost)")
     args = ap.parse_args()
@@ -122,8 +125,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     host.init(local_rank)
     host.use_torch_stream()
@@ -136,7 +140,7 @@ def main():
     model = host.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
     trainer = host.Trainer(model, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4)
     engine = dp.HostEngine(model, trainer)
-    ddp = dp.DataParallel(engine, bucket_bytes=int(args.bucket_mb * (1 << 20)))
+    ddp = dp.DataParallel(engine, bucket_bytes=int(args.bucket_mb * (1 << 20)), always_reduce=args.force_collectives)
     ddp.broadcast_parameters(0)
 
     # synthetic batch, resident in HBM: images N(0,1) (the scale of normalised MNIST), uniform labels
@@ -210,7 +214,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgd)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -83,16 +83,19 @@ def plan_buckets(ranges, bucket_bytes):
 
 
 class DataParallel:
-    def __init__(self, engine, group=None, bucket_bytes=25 << 20):
+    def __init__(self, engine, group=None, bucket_bytes=25 << 20, always_reduce=False):
+        """always_reduce: issue the collectives even with a single rank (they are then identities);
+        lets a one-GPU box exercise the same RCCL calls, streams and waits as a multi-GPU run."""
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reduce = self.world > 1 or (always_reduce and dist.is_initialized())
         ranges = [engine.stage_grad_range(s) for s in range(engine.num_stages)]
         self.buckets = plan_buckets(ranges, bucket_bytes)
         self._by_stage = {b[0]: b for b in self.buckets}
 
     def broadcast_parameters(self, src=0):
         """Start every replica from rank ``src``'s parameters."""
-        if self.world > 1:
+        if self.reduce:
             dist.broadcast(self.engine.params, src=src, group=self.group)
 
     def step(self, x, y, lr):
@@ -105,7 +108,7 @@ class DataParallel:
         for s in range(e.num_stages):
             e.backward_stage(s)
             b = self._by_stage.get(s)
-            if b is not None and self.world > 1:
+            if b is not None and self.reduce:
                 _, off, cnt = b
                 pending.append(dist.all_reduce(e.grads[off:off + cnt], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
