@@ -201,7 +201,7 @@ def main():
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": measured_traffic(dom["name"]),
                          "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes of this command "
-                                         "(profiles/r01_hbm_traffic.json); algorithmic operand bytes in DESIGN.md",
+                                         "(profiles/r01_hbm_traffic.json)",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                          "flops_per_launch": dom["flops"] / dom["launches"],
                          "all_gemm_ms_per_step": round(gemm_ms / args.steps, 3),
