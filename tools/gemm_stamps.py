@@ -54,10 +54,6 @@ print("prologue  ", q(t1 - t0))
 print("loop      ", q(t2 - t1))
 print("epilogue  ", q(t3 - t2))
 print("total     ", q(t3 - t0))
-if s[:, 8:13].any():
-    nsl = (k + 15) // 16
-    for i, name in enumerate(["first half MFMAs", "barrier", "regs->LDS (+load wait)", "global fetch issue", "second half MFMAs"]):
-        print(f"   per slab: {name:24s} {s[:, 8 + i].mean() / nsl:8.1f} cycles")
 print("loop share of lifetime %.3f, prologue %.3f, epilogue %.3f" % ((t2 - t1).sum() / (t3 - t0).sum(), (t1 - t0).sum() / (t3 - t0).sum(), (t3 - t2).sum() / (t3 - t0).sum()))
 wave_id = hw & 0xF
 simd = (hw >> 4) & 3

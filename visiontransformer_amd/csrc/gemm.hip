@@ -55,8 +55,7 @@ struct Params {
   float *colsum_ws;
   int vec_a, vec_b;
 #ifdef VITK_GEMM_STAMPS
-  unsigned long long *stamps;  // diagnostic build only: 8 clock stamps per workgroup
-  int skip_store;              // diagnostic build only: run everything but the epilogue's stores
+  unsigned long long *stamps;  // diagnostic build only: 16 slots of clock stamps per workgroup
 #endif
 };
 // Diagnostic build (-DVITK_GEMM_STAMPS, tools/gemm_stamps.py): thread 0 of every workgroup records
@@ -77,29 +76,6 @@ struct Params {
 #define VITK_STAMP(i)
 #define VITK_STAMP_AUX()
 #define VITK_STAMP_END()
-#endif
-#ifdef VITK_GEMM_STAMPS
-#define VITK_DIAG_KEEP(bit) (!(p.skip_store & (bit)))  // diagnostic build: knock out one phase (wrong results)
-#else
-#define VITK_DIAG_KEEP(bit) true
-#endif
-// Level 2: per-slab segment times accumulated into slots 8.. (perturbs the loop; attribution only).
-#if defined(VITK_GEMM_STAMPS) && VITK_GEMM_STAMPS > 1
-#define VITK_SEG_DECL() unsigned long long seg_t = __builtin_amdgcn_s_memtime(), seg_acc[5] = {0, 0, 0, 0, 0};
-#define VITK_SEG(i)                                             \
-  {                                                             \
-    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
-    seg_acc[i] += now - seg_t;                                  \
-    seg_t = now;                                                \
-  }
-#define VITK_SEG_FLUSH()                           \
-  if (p.stamps != nullptr && threadIdx.x == 0) {   \
-    for (int q = 0; q < 5; ++q) VITK_STAMP_SLOT(8 + q) = seg_acc[q]; \
-  }
-#else
-#define VITK_SEG_DECL()
-#define VITK_SEG(i)
-#define VITK_SEG_FLUSH()
 #endif
 
 // Operand whose contraction index k is contiguous in memory: element (row, k) at base[row*ld + k].
@@ -335,25 +311,19 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);  /* the next step's LDS reads ... */          \
       __builtin_amdgcn_sched_group_barrier(0x008, NT * NT, 0); /* ... then this step's MFMAs */             \
       if (ks == BK / 4 - 1) {                                                                               \
-        VITK_SEG(0)                                                                                         \
         lds_barrier();                                                                                      \
-        VITK_SEG(1)                                                                                         \
-        if ((STEADY || (T) + 2 < nslab) && VITK_DIAG_KEEP(2)) {                                             \
+        if (STEADY || (T) + 2 < nslab) {                                                                    \
           VITK_STAGE(fre, RA, RB)                                                                           \
         }                                                                                                   \
-        VITK_SEG(2)                                                                                         \
-        if ((STEADY || (T) + 4 < nslab) && VITK_DIAG_KEEP(4)) {                                             \
+        if (STEADY || (T) + 4 < nslab) {                                                                    \
           VITK_FETCH((T) + 4, RA, RB)                                                                       \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0); /* keep the loads here: sunk below the MFMAs they lose cover */ \
-        VITK_SEG(3)                                                                                         \
       }                                                                                                     \
     }                                                                                                       \
-    VITK_SEG(4)                                                                                             \
     cur = nxt;                                                                                              \
   }
 
-  VITK_SEG_DECL()
   // Column sums of B ride along: the workgroups of the first tile row add up what they stage.
   const bool do_colsum = !TB && p.colsum != nullptr && tm == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
@@ -401,7 +371,6 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     VITK_SLAB(t, ra0, rb0, false)
     if (t + 1 < nslab) VITK_SLAB(t + 1, ra1, rb1, false)
   }
-  VITK_SEG_FLUSH()
 #undef VITK_SLAB
 #undef VITK_STAGE
 #undef VITK_FIRST_OPERANDS
@@ -427,13 +396,6 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   }
 
   const int row_w = m0 + wr * WT, col_w = n0 + wc * WT;  // this wave's sub-tile origin
-#ifdef VITK_GEMM_STAMPS
-  if ((p.skip_store & 1) && acc[0][0][0] != 12345.678f) {
-    VITK_STAMP(3)
-    VITK_STAMP_END()
-    return;
-  }
-#endif
   // Epilogue.  Addresses are a uniform base plus one per-lane byte offset per pitch, so the
   // stores (and the residual / pre-activation loads) cost no vector registers for addressing.
   if constexpr (FULL) {
@@ -753,7 +715,6 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   p.vec_b = strides_vec_ok(a->B, a->ldb, a->stride_b_outer, a->stride_b_inner);
 #ifdef VITK_GEMM_STAMPS
   p.stamps = g_stamps;
-  p.skip_store = getenv("VITK_GEMM_SKIP") ? atoi(getenv("VITK_GEMM_SKIP")) : 0;
 #endif
 
   hipStream_t st = vitk::as_stream(stream);
