@@ -570,3 +570,35 @@ def test_fit_reproduces_the_reference_epoch_loop(H, tmp_path, monkeypatch):
     V.check_digest(m.get_params(), V.param_shapes(ocfg), *V.tensor_digest(p, V.param_shapes(ocfg)), 5e-5,
                    "parameters after two epochs")
     assert os.path.exists("vit_results.csv")
+
+
+def test_long_sequences_fall_back_to_the_unfused_attention_path(H):
+    """257 tokens (32x32 image, 2x2 patches) is one more than the fused attention kernels take: the
+    layer must switch to batched contractions + row softmax by itself and still match the oracle."""
+    O = V.oracle()
+    cfgd = dict(image_size=32, patch_size=2, in_channels=1, num_classes=5, embedding_dim=32, num_heads=2,
+                num_layers=1, mlp_hidden_dim=64)
+    ocfg = V.Cfg.make(**cfgd)
+    assert ocfg.tokens == 257
+    B = 3
+    prm = V.init_params(ocfg, 61)
+    x = V.rng_normal(62, B, 1, 32, 32)
+    y = V.onehot(np.arange(B) % 5, 5)
+    want_logits, want_g = V.f32(B, 5), V.f32(len(prm))
+    want_loss = O.vo_forward_backward(ocfg, prm, x, y, B, None, 0, want_logits, want_g, None)
+    m = H.Model(hcfg(H, cfgd))
+    m.set_params(prm)
+    t = H.Trainer(m)
+    t.step_forward(dev(x), dev(y))
+    for s in range(t.num_stages):
+        t.backward_stage(s)
+    loss, _ = t.result()
+    assert abs(loss - want_loss) <= 2e-5 * abs(want_loss)
+    close(host_np(m.forward(dev(x))), want_logits, ACT_TOL, "logits")
+    grads = m.get_grads()
+    off = 0
+    for i, shp in enumerate(V.param_shapes(ocfg)):
+        k = int(np.prod(shp))
+        e = V.max_relerr(grads[off:off + k], want_g[off:off + k], floor=1e-6)
+        assert e <= GRAD_TOL, f"grad tensor {i} {shp}: {e:.3e}"
+        off += k
