@@ -493,7 +493,8 @@ def heads_of(x, B, N, H, dh, col0):
 
 @pytest.mark.parametrize("B,H,N,dh,pad", [(2, 3, 197, 64, 0), (3, 8, 5, 12, 0), (2, 6, 17, 32, 0), (1, 2, 256, 64, 0),
                                           (2, 2, 33, 20, 1), (1, 1, 1, 4, 0), (2, 4, 50, 16, 0), (1, 3, 129, 48, 3),
-                                          (2, 2, 64, 7, 0)])
+                                          (2, 2, 64, 7, 0), (2, 2, 100, 48, 0), (1, 4, 33, 64, 0), (1, 1, 1, 64, 0),
+                                          (3, 2, 224, 40, 0)])
 @pytest.mark.parametrize("dk_mode", ["reference", "exact"])
 def test_sdpa_fused_matches_float64(K, B, H, N, dh, pad, dk_mode):
     D, M = H * dh, B * N

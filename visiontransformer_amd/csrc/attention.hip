@@ -1,5 +1,7 @@
 // Fused multi-head scaled-dot-product attention on the CDNA4 fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32): forward, and the backward as two kernels (query side, key side).
+// (v_mfma_f32_32x32x2_f32): forward, and the backward either as one kernel per head (head
+// dimensions 33..64, the ViT case) or as two kernels (query side, key side) for smaller heads and
+// unaligned operands.
 // Replaces the chain   scores = Q K^T * scale -> softmax -> P V   and its backward
 // (reference: src/layers/MultiHeadAttention.cpp:96-156 forward, :160-308 backward) without ever
 // writing the [B*h][N][N] score / probability / gradient matrices to memory: the forward keeps
@@ -264,6 +266,30 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_fwd_kernel(const SdpaParams p
     store_rows<DT, VEC>(p.out + ((long long)b * p.N + q0 + li) * p.ldo + (long long)h * p.dh, o, p.dh, lh);
 }
 
+// Stores of one key row's dV and dK (transposed accumulators), dK in the layout dk_mode asks for.
+template <int DT, bool VEC>
+__device__ __forceinline__ void store_key_grads(const SdpaParams &p, int b, int h, int key, int lh,
+                                                const f32x16 (&dk)[DT], const f32x16 (&dv)[DT]) {
+  store_rows<DT, VEC>(p.dv + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dv, p.dh, lh);
+  if (p.dk_mode == VITK_DK_EXACT) {
+    store_rows<DT, VEC>(p.dk + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dk, p.dh, lh);
+  } else {
+    // The reference forms Q^T dS as [dh][N] per head and re-reads that buffer as [N][dh]
+    // (src/layers/MultiHeadAttention.cpp:207-222): element (d, key) lands at flat index d*N + key.
+    float *base = p.dk + (long long)b * p.N * p.ldg + (long long)h * p.dh;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = 32 * t + VITK_ROW_OF(r) + 4 * lh;
+        if (d < p.dh) {
+          const int f = d * p.N + key;
+          base[(long long)(f / p.dh) * p.ldg + f % p.dh] = dk[t][r];
+        }
+      }
+  }
+}
+
 // ---- backward, query side: dQ (and dsum = rowsum(dO*O) for the key side) --------------------------
 // Per key tile: S^T = K Q^T and dP^T = V dO^T (both [key][query]), P from the saved row statistics,
 // dS^T = P^T (dP^T - dsum) * scale, dQ^T[d][query] += K^T dS^T with dS^T as operand B.
@@ -470,24 +496,163 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaPara
 #undef VITK_LOAD_STATS
 #undef VITK_STORE_STAGE
   if (!active || !key_ok) return;
-  store_rows<DT, VEC>(p.dv + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dv, p.dh, lh);
-  if (p.dk_mode == VITK_DK_EXACT) {
-    store_rows<DT, VEC>(p.dk + ((long long)b * p.N + key) * p.ldg + (long long)h * p.dh, dk, p.dh, lh);
-  } else {
-    // The reference forms Q^T dS as [dh][N] per head and re-reads that buffer as [N][dh]
-    // (src/layers/MultiHeadAttention.cpp:207-222): element (d, key) lands at flat index d*N + key.
-    float *base = p.dk + (long long)b * p.N * p.ldg + (long long)h * p.dh;
+  store_key_grads<DT, VEC>(p, b, h, key, lh, dk, dv);
+}
+
+// ---- backward, one workgroup per head (32 < dh <= 64, 16-byte accesses, N <= 256) ------------------
+// Eight waves, wave w owns keys 32w .. 32w+31 (dK, dV accumulators and its K / V fragments live in
+// registers for the whole kernel); the query tiles stream through LDS.  Per query tile every wave
+// forms S and dP of its (query tile x key tile) block ONCE (plain, [query][key]) and uses them
+// three ways: dV += dO^T P and dK += Q^T dS straight from registers (operand B), and -- after a
+// 4 KB transpose of dS through a wave-private LDS buffer -- its share of dQ^T = K^T dS^T.  The
+// eight partial dQ tiles are summed in a fixed order through LDS.  10 N^2 dh FLOP per head instead
+// of the 14 of the two-kernel form, no row-sum pre-pass (sum_d dO*O is formed while staging).
+constexpr int FT = 512;
+constexpr int F_TILE = 2 * (64 * PT) + 2 * (32 * 64) + 96;  // Q^T, dO^T, Q, dO, {max, 1/sum, dsum}[32]
+constexpr int F_TB = 32 * PT;                               // dS transpose buffer of one wave
+constexpr int F_RBP = 68;                                   // pitch of a partial dQ tile [query][d]
+constexpr int F_RB = 32 * F_RBP;
+constexpr int F_LDS_FLOATS = F_TILE + 8 * F_TB + 8 * F_RB;
+
+__global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams p) {
+  constexpr int HALF = 32, DT = 2, PW = 64, TRANS = 64 * PT, PLAIN = 32 * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int k0 = wave * 32, key = k0 + li;
+  const bool active = k0 < p.N, key_ok = key < p.N;
+  const int nt = (p.N + 31) / 32;  // query tiles = key tiles = active waves
+  const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
+  const long long ohead = (long long)b * p.N * p.ldo + (long long)h * p.dh;
+  const float *Q = p.q + head, *K = p.k + head, *V = p.v + head;
+  const float *DO = p.dout + ohead, *O = p.o + ohead;
+  float *tile = lds, *tb = lds + F_TILE + wave * F_TB, *rb_all = lds + F_TILE + 8 * F_TB;
+
+  // this wave's key tile: fragments for S = Q K^T / dP = dO V^T (operand B) and K rows for
+  // dQ^T = K^T dS^T (operand A: K[key(r, lh)][li + 32t])
+  float kf[HALF], vf[HALF], kpl[32];
+  load_fragment<64, true>(K, p.ld, key, p.N, p.dh, lh, kf);
+  load_fragment<64, true>(V, p.ld, key, p.N, p.dh, lh, vf);
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+  for (int r = 0; r < 16; ++r)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int d = 32 * t + VITK_ROW_OF(r) + 4 * lh;
-        if (d < p.dh) {
-          const int f = d * p.N + key;
-          base[(long long)(f / p.dh) * p.ldg + f % p.dh] = dk[t][r];
+    for (int t = 0; t < DT; ++t) {
+      const int row = k0 + VITK_ROW_OF(r) + 4 * lh, col = li + 32 * t;
+      const float x = K[(long long)min(row, p.N - 1) * p.ld + min(col, p.dh - 1)];
+      kpl[2 * r + t] = (row < p.N && col < p.dh) ? x : 0.f;
+    }
+  f32x16 dk[DT], dv[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) dk[t] = zero16(), dv[t] = zero16();
+
+  // staging: thread t moves columns 4*(t%16) .. +3 of row t/16 of the Q, dO and O tiles
+  const int lr = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 4;
+  const bool col_ok = c0 < p.dh;
+  const int cc = col_ok ? c0 : 0;
+  f32x4 rq, rg, ro;
+  float st_max = 0.f, st_sum = 1.f;
+  bool row_ok = false;
+#define VITK_LOAD_TILE(I)                                                                  \
+  {                                                                                        \
+    const int row = 32 * (I) + lr, rc = min(row, p.N - 1);                                 \
+    row_ok = row < p.N;                                                                    \
+    rq = *reinterpret_cast<const f32x4 *>(Q + (long long)rc * p.ld + cc);                  \
+    rg = *reinterpret_cast<const f32x4 *>(DO + (long long)rc * p.ldo + cc);                \
+    ro = *reinterpret_cast<const f32x4 *>(O + (long long)rc * p.ldo + cc);                 \
+    st_max = p.stats[((long long)bh * p.N + rc) * 2];                                      \
+    st_sum = p.stats[((long long)bh * p.N + rc) * 2 + 1];                                  \
+  }
+#define VITK_STORE_TILE()                                                                  \
+  {                                                                                        \
+    const bool ok = row_ok && col_ok;                                                      \
+    float part = 0.f;                                                                      \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+      rq[e] = ok ? rq[e] : 0.f;                                                            \
+      rg[e] = ok ? rg[e] : 0.f;                                                            \
+      part += ok ? rg[e] * ro[e] : 0.f;                                                    \
+      tile[(c0 + e) * PT + lr] = rq[e];                                                    \
+      tile[TRANS + (c0 + e) * PT + lr] = rg[e];                                            \
+    }                                                                                      \
+    *reinterpret_cast<f32x4 *>(tile + 2 * TRANS + lr * PW + c0) = rq;                      \
+    *reinterpret_cast<f32x4 *>(tile + 2 * TRANS + PLAIN + lr * PW + c0) = rg;              \
+    _Pragma("unroll") for (int m = 8; m > 0; m >>= 1) part += __shfl_xor(part, m, 16);     \
+    if ((threadIdx.x & 15) == 0) {                                                         \
+      float *ss = tile + 2 * TRANS + 2 * PLAIN;                                            \
+      ss[lr] = row_ok ? st_max : 0.f;                                                      \
+      ss[32 + lr] = row_ok ? 1.0f / st_sum : 0.f;                                          \
+      ss[64 + lr] = row_ok ? part : 0.f;                                                   \
+    }                                                                                      \
+  }
+  VITK_LOAD_TILE(0)
+  VITK_STORE_TILE()
+  __syncthreads();
+  for (int i = 0; i < nt; ++i) {
+    if (i + 1 < nt) VITK_LOAD_TILE(i + 1)
+    if (active) {
+      const float *qt = tile + (HALF * lh) * PT + li, *gt = qt + TRANS;
+      const float *qp = tile + 2 * TRANS + (4 * lh) * PW + li, *gp = qp + PLAIN;
+      const float *ss = tile + 2 * TRANS + 2 * PLAIN + 4 * lh;
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int jj = 0; jj < HALF; ++jj) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qt[jj * PT], kf[jj], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[jj * PT], vf[jj], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ss + 8 * g);
+        const f32x4 i4 = *reinterpret_cast<const f32x4 *>(ss + 32 + 8 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(ss + 64 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pr = key_ok ? __expf(s[r] * p.scale - m4[e]) * i4[e] : 0.f;
+          s[r] = pr;
+          dp[r] = (pr * (dp[r] - d4[e])) * p.scale;
+          tb[li * PT + VITK_ROW_OF(r) + 4 * lh] = dp[r];  // dS[query][key] -> tb[key][query]
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          dv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[VITK_ROW_OF(r) * PW + 32 * t], s[r], dv[t], 0, 0, 0);
+          dk[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[VITK_ROW_OF(r) * PW + 32 * t], dp[r], dk[t], 0, 0, 0);
+        }
+      // this wave's share of dQ^T[d][query] = sum over its keys of K[key][d] dS^T[key][query]
+      f32x16 dq[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) dq[t] = zero16();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dst = tb[(VITK_ROW_OF(r) + 4 * lh) * PT + li];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kpl[2 * r + t], dst, dq[t], 0, 0, 0);
+      }
+      float *rb = rb_all + wave * F_RB + li * F_RBP + 4 * lh;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {dq[t][4 * g], dq[t][4 * g + 1], dq[t][4 * g + 2], dq[t][4 * g + 3]};
+          *reinterpret_cast<f32x4 *>(rb + 32 * t + 8 * g) = v;
+        }
+    }
+    __syncthreads();  // every wave is done with this query tile; all partial dQ tiles are in LDS
+    if (i + 1 < nt) VITK_STORE_TILE()
+    {
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < nt; ++w) sum += *reinterpret_cast<const f32x4 *>(rb_all + w * F_RB + lr * F_RBP + c0);
+      const int row = 32 * i + lr;
+      if (row < p.N && col_ok)
+        *reinterpret_cast<f32x4 *>(p.dq + ((long long)b * p.N + row) * p.ldg + (long long)h * p.dh + c0) = sum;
+    }
+    __syncthreads();  // next query tile staged; partial buffers free again
   }
+#undef VITK_LOAD_TILE
+#undef VITK_STORE_TILE
+  if (!active || !key_ok) return;
+  store_key_grads<DT, true>(p, b, h, key, lh, dk, dv);
 }
 
 template <int DHP, bool VEC>
@@ -514,6 +679,19 @@ int launch_bwd(const SdpaParams &p, dim3 grid, hipStream_t st) {
   }
   hipLaunchKernelGGL((sdpa_bwd_dq_kernel<DHP, VEC>), grid, dim3(THREADS), 0, st, p);
   hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<DHP, VEC>), grid, dim3(THREADS), lds, st, p);
+  return vitk::check_launch("vitk_sdpa_bwd");
+}
+
+int launch_bwd_fused(const SdpaParams &p, hipStream_t st) {
+  const size_t lds = F_LDS_FLOATS * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd_fused_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    VITK_REQUIRE(e == hipSuccess, "vitk_sdpa_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(sdpa_bwd_fused_kernel, dim3((unsigned)(p.B * p.H)), dim3(FT), lds, st, p);
   return vitk::check_launch("vitk_sdpa_bwd");
 }
 
@@ -584,7 +762,7 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   if (!p.vec) return launch_bwd<64, false>(p, grid, st);
   if (dh <= 16) return launch_bwd<16, true>(p, grid, st);
   if (dh <= 32) return launch_bwd<32, true>(p, grid, st);
-  return launch_bwd<64, true>(p, grid, st);
+  return launch_bwd_fused(p, st);  // 32 < dh <= 64: one workgroup per head
 }
 
 }  // extern "C"
