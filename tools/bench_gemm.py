@@ -1,9 +1,13 @@
 """Micro-benchmark of vitk_gemm_f32 on the ViT GEMM shapes (TFLOP/s vs the 157.3 TF fp32 matrix peak)."""
+import os
 import sys
 import torch
 
 from visiontransformer_amd import vitk
 
+if len(sys.argv) > 2 and sys.argv[1] == "--lib":  # --lib <file name in visiontransformer_amd/lib> (diagnostic builds)
+    vitk.LIB_PATH = os.path.join(os.path.dirname(vitk.LIB_PATH), sys.argv[2])
+    del sys.argv[1:3]
 vitk.init(0)
 M = 50432
 shapes = [

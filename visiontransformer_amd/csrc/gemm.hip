@@ -1,21 +1,27 @@
-// fp32 GEMM family on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32): NN / NT / TN / TT, batched,
-// fused epilogues, deterministic split-K.  Entry points: vitk_gemm_f32, vitk_gemm_workspace_bytes.
+// fp32 GEMM family on the CDNA4 matrix cores: NN / NT / TN / TT, batched, fused epilogues,
+// deterministic split-K.  Entry points: vitk_gemm_f32, vitk_gemm_workspace_bytes.
 //
 // Structure of one workgroup (256 threads = 4 waves, one per SIMD, arranged 2 x 2):
-//   * output tile TILE x TILE (128 or 64); each wave owns a (TILE/2)^2 sub-tile = NT x NT MFMA tiles
-//     of 32x32, accumulators live in registers for the whole K loop;
+//   * output tile TILE x TILE (128 or 64); each wave owns a (TILE/2)^2 sub-tile whose accumulators
+//     live in registers for the whole K loop;
+//   * problems made of whole tiles with 16-byte-aligned operands (every large contraction of
+//     ViT-Ti/S/B) run on v_mfma_f32_16x16x4_f32 with transposed accumulators (16-byte stores) and
+//     read global memory through buffer descriptors; everything else runs on v_mfma_f32_32x32x2_f32
+//     with plain accumulators and bounds checks.  Both instructions issue 64 FLOP/clk/SIMD, but
+//     16x16x4 contracts 4 k per pass over the accumulators -- half the accumulator-file traffic
+//     per FLOP -- and the chip holds a measurably higher clock under it (+5 % throughput);
 //   * the K loop walks BK = 16 deep slabs through a three-slot LDS ring: while slab t is multiplied,
-//     slab t+2 moves registers->LDS and slab t+3 global->registers (16-byte loads); the one barrier
-//     per slab sits in the middle of the slab's MFMAs, so operand reads never wait at a slab
-//     boundary and global latency hides behind more than a slab of MFMAs;
-//   * both operands sit in LDS as [k][m|n] so that an MFMA operand read is one conflict-free
-//     ds_read_b32 per lane (lane l reads element [k0 + l/32][i0 + l%32]).  Operands whose
-//     contraction index is contiguous in memory are transposed on the LDS write; the row pitch
-//     (TILE+2 for those, TILE+4 for the others) keeps both kinds of write conflict-free.
-// The fp32 MFMA issues at 64 FLOP/clk/SIMD (a 32x32x2 takes 64 cycles), so per wave and k-step of
-// 2 the LDS traffic is only 2*NT operand reads against NT^2 MFMAs: the loop is MFMA-paced.
+//     slab t+2 moves registers->LDS and slabs t+3, t+4 global->registers (16-byte loads); the one
+//     barrier per slab sits in the middle of the slab's MFMAs, so operand reads never wait at a
+//     slab boundary and global latency hides behind two slabs of MFMAs;
+//   * both operands sit in LDS as [k][m|n] with a row pitch of TILE+4 floats, so that an MFMA
+//     operand read is one conflict-free ds_read_b32 per lane.  Operands whose contraction index is
+//     contiguous in memory are transposed on the LDS write (2-way, which costs nothing).
+// Per wave and MFMA step the LDS traffic is only 2*T operand reads against T^2 MFMAs (T tiles per
+// sub-tile edge): the loop is MFMA-paced.
 #include "common.h"
 
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -30,6 +36,7 @@ constexpr int STAGES = 3;  // LDS ring depth (slabs)
 // Workgroups resident per CU (= waves per SIMD) the kernels are compiled for; the split-K plan
 // sizes its grid to one full round of these.
 constexpr int kBlocksPerCU = 3;
+
 
 struct Params {
   int M, N, K;
@@ -83,7 +90,7 @@ struct Params {
 template <int ROWS>
 struct KContig {
   static constexpr int NL = ROWS * BK / 4 / THREADS;
-  static constexpr int LD = ROWS + 2;
+  static constexpr int LD = ROWS + 4;  // k-rows 4 apart land 16 banks apart (see the operand reads)
   __device__ static void load(const float *__restrict__ base, long long ld, int row0, int rows, int k0, int kend,
                               bool vec, f32x4 (&reg)[NL]) {
 #pragma unroll
@@ -198,7 +205,6 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   using OpA = Operand<!TA, TILE>;  // A is k-contiguous when not transposed
   using OpB = Operand<TB, TILE>;   // B is k-contiguous when transposed
   constexpr int WT = TILE / 2;     // per-wave tile
-  constexpr int NT = WT / 32;      // MFMA tiles per wave per dimension
   constexpr int SA = BK * OpA::LD, SB = BK * OpB::LD;
   __shared__ __attribute__((aligned(16))) float As[STAGES * SA];
   __shared__ __attribute__((aligned(16))) float Bs[STAGES * SB];
@@ -233,34 +239,48 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  f32x16 acc[NT][NT];
+  // FULL runs on v_mfma_f32_16x16x4_f32 (one instruction contracts 4 k, so the accumulator file
+  // is read and written half as often per FLOP as with 32x32x2 and the chip holds a higher clock
+  // under load); the guarded path keeps 32x32x2, whose plain accumulator layout stores whole
+  // 128-byte row segments at any alignment.
+  constexpr int TW = FULL ? 16 : 32;            // MFMA tile edge
+  constexpr int NTX = WT / TW;                  // MFMA tiles per wave per dimension
+  constexpr int KSTEP = FULL ? 4 : 2;           // k per MFMA step
+  constexpr int STEPS = BK / KSTEP;             // MFMA steps per slab
+  constexpr int KROW = FULL ? 1 : 2;            // LDS k-rows between the operand reads of successive steps
+  using AccT = std::conditional_t<FULL, f32x4, f32x16>;
+  AccT acc[NTX][NTX];
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NTX; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTX; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < (FULL ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra0[OpA::NL], rb0[OpB::NL], ra1[OpA::NL], rb1[OpB::NL];  // two slabs in flight
   const bool va = p.vec_a, vb = p.vec_b;
-  // FULL: uniform tile-origin pointers (scalar registers) + constant per-lane byte offsets
+  // FULL: each operand is read through a buffer descriptor based at the tile origin (scalar
+  // registers), a per-lane 32-bit byte offset that is constant over the K loop and a scalar offset
+  // that advances by one slab -- no vector address arithmetic and no 64-bit address registers.
   unsigned offa[OpA::NL], offb[OpB::NL];
-  const char *pa = reinterpret_cast<const char *>(A + OpA::origin(p.lda, m0, kbeg));
-  const char *pb = reinterpret_cast<const char *>(B + OpB::origin(p.ldb, n0, kbeg));
-  const long long step_a = OpA::slab_bytes(p.lda), step_b = OpB::slab_bytes(p.ldb);
+  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+  int so_a = 0, so_b = 0;
+  const int step_a = (int)OpA::slab_bytes(p.lda), step_b = (int)OpB::slab_bytes(p.ldb);
   if constexpr (FULL) {
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + OpA::origin(p.lda, m0, kbeg)), 0, -1, 0x00020000);
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + OpB::origin(p.ldb, n0, kbeg)), 0, -1, 0x00020000);
     OpA::lane_offsets(p.lda, offa);
     OpB::lane_offsets(p.ldb, offb);
   }
 // (a macro rather than a lambda: arrays captured by reference end up in scratch memory)
 #define VITK_FETCH(T, RA, RB)                                                                               \
   if constexpr (FULL) {                                                                                     \
-    _Pragma("unroll") for (int it = 0; it < OpA::NL; ++it) RA[it] =                                         \
-        *reinterpret_cast<const f32x4 *>(pa + offa[it]);                                                   \
-    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) RB[it] =                                         \
-        *reinterpret_cast<const f32x4 *>(pb + offb[it]);                                                   \
-    pa += step_a;                                                                                           \
-    pb += step_b;                                                                                           \
+    _Pragma("unroll") for (int it = 0; it < OpA::NL; ++it) RA[it] = __builtin_bit_cast(                     \
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, offa[it], so_a, 0));                           \
+    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) RB[it] = __builtin_bit_cast(                     \
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, offb[it], so_b, 0));                           \
+    so_a += step_a;                                                                                         \
+    so_b += step_b;                                                                                         \
   } else {                                                                                                  \
     OpA::load(A, p.lda, m0, p.M, kbeg + (T)*BK, kend, va, RA);                                              \
     OpB::load(B, p.ldb, n0, p.N, kbeg + (T)*BK, kend, vb, RB);                                              \
@@ -272,16 +292,22 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   // The single barrier of a slab sits in its MIDDLE: a wave that has passed it knows every wave
   // is done with slab t-1 (so its slot may be overwritten) and that slab t+1 is completely
   // written (so operand reads run across the slab boundary without a stall).
-  const int lane_a = wr * WT + li + lh * OpA::LD, lane_b = wc * WT + li + lh * OpB::LD;
+  // Operand lanes.  32x32x2: lane (li, lh) supplies row li at k = 2*step + lh.  16x16x4: lane
+  // (l16, g) supplies row l16 at the g-th of the step's four k; which four is free as long as both
+  // operands agree, and k = step + 4*(g&1) + 8*(g>>1) puts the two 16-lane groups that share an
+  // LDS cycle 4 k-rows = 16 banks apart (both pitches are 4 mod 32), i.e. conflict-free.
+  const int l16 = lane & 15, g16 = lane >> 4, kofs = 4 * (g16 & 1) + 8 * (g16 >> 1);
+  const int lane_a = FULL ? wr * WT + l16 + kofs * OpA::LD : wr * WT + li + lh * OpA::LD;
+  const int lane_b = FULL ? wc * WT + l16 + kofs * OpB::LD : wc * WT + li + lh * OpB::LD;
   int cur = 0;  // ring slot of slab t
   int t = 0;
   // Operand reads run one k-step ahead of the MFMAs that consume them (two register sets).
-  float a[2][NT], b[2][NT];
+  float a[2][NTX], b[2][NTX];
 #define VITK_FIRST_OPERANDS()                                                             \
   lds_barrier();                                                                          \
   VITK_STAMP(1)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < NT; ++i) a[0][i] = As[lane_a + i * 32];           \
-  _Pragma("unroll") for (int j = 0; j < NT; ++j) b[0][j] = Bs[lane_b + j * 32];
+  _Pragma("unroll") for (int i = 0; i < NTX; ++i) a[0][i] = As[lane_a + i * TW];          \
+  _Pragma("unroll") for (int j = 0; j < NTX; ++j) b[0][j] = Bs[lane_b + j * TW];
 
   // One slab (index T, prefetch registers RA/RB hold slab T+2 on entry, slab T+4 on exit;
   // STEADY: slabs T+2 and T+4 are known to exist).
@@ -296,21 +322,22 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     const float *__restrict__ bs = Bs + cur * SB + lane_b;                                                  \
     const float *__restrict__ as_n = As + nxt * SA + lane_a;                                                \
     const float *__restrict__ bs_n = Bs + nxt * SB + lane_b;                                                \
-    _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < STEPS; ++ks) {                                                  \
       const int c = ks & 1, n = c ^ 1;                                                                      \
-      if (ks + 1 < BK / 2) {                                                                                \
-        _Pragma("unroll") for (int i = 0; i < NT; ++i) a[n][i] = as[(2 * ks + 2) * OpA::LD + i * 32];       \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) b[n][j] = bs[(2 * ks + 2) * OpB::LD + j * 32];       \
+      if (ks + 1 < STEPS) {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NTX; ++i) a[n][i] = as[KROW * (ks + 1) * OpA::LD + i * TW];   \
+        _Pragma("unroll") for (int j = 0; j < NTX; ++j) b[n][j] = bs[KROW * (ks + 1) * OpB::LD + j * TW];   \
       } else { /* first k-step of the next slab (after the last slab: a harmless stale read) */             \
-        _Pragma("unroll") for (int i = 0; i < NT; ++i) a[n][i] = as_n[i * 32];                              \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) b[n][j] = bs_n[j * 32];                              \
+        _Pragma("unroll") for (int i = 0; i < NTX; ++i) a[n][i] = as_n[i * TW];                             \
+        _Pragma("unroll") for (int j = 0; j < NTX; ++j) b[n][j] = bs_n[j * TW];                             \
       }                                                                                                     \
-      _Pragma("unroll") for (int i = 0; i < NT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j)         \
-          acc[i][j] = FULL ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[c][j], a[c][i], acc[i][j], 0, 0, 0)     \
-                           : __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);    \
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);  /* the next step's LDS reads ... */          \
-      __builtin_amdgcn_sched_group_barrier(0x008, NT * NT, 0); /* ... then this step's MFMAs */             \
-      if (ks == BK / 4 - 1) {                                                                               \
+      _Pragma("unroll") for (int i = 0; i < NTX; ++i) _Pragma("unroll") for (int j = 0; j < NTX; ++j) {     \
+        if constexpr (FULL) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][j], a[c][i], acc[i][j], 0, 0, 0); \
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);        \
+      }                                                                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NTX, 0);   /* the next step's LDS reads ... */        \
+      __builtin_amdgcn_sched_group_barrier(0x008, NTX * NTX, 0); /* ... then this step's MFMAs */           \
+      if (ks == STEPS / 2 - 1) {                                                                               \
         lds_barrier();                                                                                      \
         if (STEADY || (T) + 2 < nslab) {                                                                    \
           VITK_STAGE(fre, RA, RB)                                                                           \
@@ -331,7 +358,7 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   OpA::store(As + (SLOT)*SA, RA);                                                         \
   OpB::store(Bs + (SLOT)*SB, RB);                                                         \
   if constexpr (!TB) {                                                                    \
-    if (do_colsum) { _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) csum += RB[it]; } \
+    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) csum += RB[it]; /* used only if do_colsum */ \
   }
 
   // Long contractions: a straight-line prologue and a condition-free steady state in ONE branch,
@@ -399,59 +426,52 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   // Epilogue.  Addresses are a uniform base plus one per-lane byte offset per pitch, so the
   // stores (and the residual / pre-activation loads) cost no vector registers for addressing.
   if constexpr (FULL) {
-    // Transposed accumulators: registers 4g..4g+3 of lane l hold C[l&31][8g + 4*(l>>5) + 0..3] of
-    // the 32x32 tile -- one 16-byte store per lane and g.
+    // Transposed accumulators: lane l of the 16x16 tile holds C[l&15][4*(l>>4) + 0..3] -- one
+    // 16-byte store per lane and tile, 64 contiguous bytes per row and instruction.
     if (p.split_k > 1) {
       char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
-      const unsigned lane_w = (unsigned)((li * (long long)p.N + 4 * lh) * 4);
+      const unsigned lane_w = (unsigned)((l16 * (long long)p.N + 4 * g16) * 4);
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NTX; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-            *reinterpret_cast<f32x4 *>(W + ((long long)(i * 32) * p.N + j * 32 + 8 * g) * 4 + lane_w) = v;
-          }
+        for (int j = 0; j < NTX; ++j)
+          *reinterpret_cast<f32x4 *>(W + ((long long)(i * 16) * p.N + j * 16) * 4 + lane_w) = acc[i][j];
     } else {
       char *C = reinterpret_cast<char *>(p.C + bo * p.sc_o + bi * p.sc_i + (long long)row_w * p.ldc + col_w);
       const char *R =
           reinterpret_cast<const char *>(p.residual ? p.residual + (long long)row_w * p.ldr + col_w : nullptr);
       char *X = reinterpret_cast<char *>(p.aux ? p.aux + (long long)row_w * p.ldaux + col_w : nullptr);
-      const unsigned lane_c = (unsigned)((li * p.ldc + 4 * lh) * 4);
-      const unsigned lane_r = (unsigned)((li * p.ldr + 4 * lh) * 4);
-      const unsigned lane_x = (unsigned)((li * p.ldaux + 4 * lh) * 4);
+      const unsigned lane_c = (unsigned)((l16 * p.ldc + 4 * g16) * 4);
+      const unsigned lane_r = (unsigned)((l16 * p.ldr + 4 * g16) * 4);
+      const unsigned lane_x = (unsigned)((l16 * p.ldaux + 4 * g16) * 4);
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NTX; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTX; ++j) {
+          const int col = col_w + j * 16 + 4 * g16;
+          f32x4 *cp = reinterpret_cast<f32x4 *>(C + ((long long)(i * 16) * p.ldc + j * 16) * 4 + lane_c);
+          f32x4 *xp = reinterpret_cast<f32x4 *>(X + ((long long)(i * 16) * p.ldaux + j * 16) * 4 + lane_x);
+          const f32x4 *rp = reinterpret_cast<const f32x4 *>(R + ((long long)(i * 16) * p.ldr + j * 16) * 4 + lane_r);
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f}, xv = bv, rv = bv, v, pre;
+          if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(p.bias + col);
+          if (p.act == VITK_ACT_GELU_BWD) xv = *xp;
+          if (p.residual != nullptr) rv = *rp;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int col = col_w + j * 32 + 8 * g + 4 * lh;
-            f32x4 *cp = reinterpret_cast<f32x4 *>(C + ((long long)(i * 32) * p.ldc + j * 32 + 8 * g) * 4 + lane_c);
-            f32x4 *xp = reinterpret_cast<f32x4 *>(X + ((long long)(i * 32) * p.ldaux + j * 32 + 8 * g) * 4 + lane_x);
-            const f32x4 *rp =
-                reinterpret_cast<const f32x4 *>(R + ((long long)(i * 32) * p.ldr + j * 32 + 8 * g) * 4 + lane_r);
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, xv = bv, rv = bv, v, pre;
-            if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(p.bias + col);
-            if (p.act == VITK_ACT_GELU_BWD) xv = *xp;
-            if (p.residual != nullptr) rv = *rp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float y = p.alpha * acc[i][j][4 * g + e];
-              if (p.act == VITK_ACT_GELU_BWD) y *= vitk::gelu_grad(xv[e]);
-              y += bv[e];
-              pre[e] = y;
-              if (p.act == VITK_ACT_GELU_FWD) y = vitk::gelu_fwd(y);
-              if (p.residual != nullptr) y += rv[e];
-              v[e] = y;
-            }
-            if (p.act == VITK_ACT_GELU_FWD && p.aux != nullptr) *xp = pre;
-            *cp = v;
+          for (int e = 0; e < 4; ++e) {
+            float y = p.alpha * acc[i][j][e];
+            if (p.act == VITK_ACT_GELU_BWD) y *= vitk::gelu_grad(xv[e]);
+            y += bv[e];
+            pre[e] = y;
+            if (p.act == VITK_ACT_GELU_FWD) y = vitk::gelu_fwd(y);
+            if (p.residual != nullptr) y += rv[e];
+            v[e] = y;
           }
-          // keep the loads of one 32x32 tile from being hoisted above the stores of the previous one
-          asm volatile("" ::: "memory");
+          if (p.act == VITK_ACT_GELU_FWD && p.aux != nullptr) *xp = pre;
+          *cp = v;
         }
+        // keep the loads of one 16-row band from being hoisted above the stores of the previous one
+        asm volatile("" ::: "memory");
+      }
     }
   } else {
     // Plain accumulators: register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of the
@@ -461,9 +481,9 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
       const unsigned lane_w = (unsigned)((4 * lh * (long long)p.N + li) * 4);
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NTX; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTX; ++j) {
           const int col = col_w + j * 32 + li;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -482,9 +502,9 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       const unsigned lane_r = (unsigned)((4 * lh * p.ldr + li) * 4);
       const unsigned lane_x = (unsigned)((4 * lh * p.ldaux + li) * 4);
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NTX; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NTX; ++j) {
           const int col = col_w + j * 32 + li;
           const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
@@ -722,6 +742,8 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   // every K chunk starts and ends on a slab boundary when K and the chunk are multiples of BK
   const bool full = p.vec_a && p.vec_b && a->M % pl.tile == 0 && a->N % pl.tile == 0 && a->K > 0 &&
                     a->K % BK == 0 && pl.k_chunk % BK == 0 && a->lda < (1 << 21) && a->ldb < (1 << 21) &&
+                    (!a->trans_a || (long long)(a->K + BK) * a->lda * 4 < (1ll << 31)) &&
+                    (a->trans_b || (long long)(a->K + BK) * a->ldb * 4 < (1ll << 31)) &&
                     a->ldc < (1 << 21) && a->ldr < (1 << 21) && a->ldaux < (1 << 21) &&
                     strides_vec_ok(a->C, a->ldc, a->stride_c_outer, a->stride_c_inner) &&
                     (a->residual == nullptr || strides_vec_ok(a->residual, a->ldr, 0, 0)) &&
