@@ -204,27 +204,38 @@ __global__ void ln_param_grad_generic(const float *__restrict__ dy, const float 
 }
 
 // Second stage of every cross-row reduction in this file: out[c] = sum_k partial[k*pitch + c] for
-// k in [0, n), in a fixed order.  A workgroup owns 64 columns; its 4 waves each sum every fourth
-// partial row (coalesced 256-byte reads) and the four sums are combined through LDS.
-constexpr int RED_COLS = 64;
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int n,
-                                                              long long pitch, long long cols,
-                                                              float *__restrict__ out) {
-  __shared__ float sm[4][RED_COLS];
+// k in [0, n), in a fixed order; columns at and beyond `split` go to out2[c - split] (layer norm
+// reduces its gamma and beta partials, which share a row, in one launch).  A workgroup owns 64
+// columns; its 16 waves each sum every sixteenth partial row (coalesced 256-byte reads, four
+// independent chains) and the sixteen sums are combined through LDS.
+constexpr int RED_COLS = 64, RED_WAVES = 16;
+__global__ __launch_bounds__(RED_COLS * RED_WAVES) void reduce_partials_kernel(
+    const float *__restrict__ partial, int n, long long pitch, long long cols, long long split,
+    float *__restrict__ out, float *__restrict__ out2) {
+  __shared__ float sm[RED_WAVES][RED_COLS];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long long c = (long long)blockIdx.x * RED_COLS + lane;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < cols) {
+    const float *__restrict__ col = partial + c;
     int k = g;
-    for (; k + 4 < n; k += 8) {
-      s0 += partial[(long long)k * pitch + c];
-      s1 += partial[(long long)(k + 4) * pitch + c];
+    for (; k + 3 * RED_WAVES < n; k += 4 * RED_WAVES) {
+      s0 += col[(long long)k * pitch];
+      s1 += col[(long long)(k + RED_WAVES) * pitch];
+      s2 += col[(long long)(k + 2 * RED_WAVES) * pitch];
+      s3 += col[(long long)(k + 3 * RED_WAVES) * pitch];
     }
-    if (k < n) s0 += partial[(long long)k * pitch + c];
+    for (; k < n; k += RED_WAVES) s0 += col[(long long)k * pitch];
   }
-  sm[g][lane] = s0 + s1;
+  sm[g][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (g == 0 && c < cols) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+  if (g == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < RED_WAVES; ++w) t += sm[w][lane];
+    if (c < split) out[c] = t;
+    else out2[c - split] = t;
+  }
 }
 
 // ---- column sum -------------------------------------------------------------------------------
@@ -248,7 +259,7 @@ __global__ void colsum_stage1(const float *__restrict__ x, long long rows, long 
 
 int ln_blocks(long long rows) {
   long long b = (rows + WPB - 1) / WPB;
-  if (b > 512) b = 512;
+  if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -300,8 +311,9 @@ int vitk_colsum_f32(const float *x, int64_t rows, int64_t cols, int64_t ldx, flo
   hipLaunchKernelGGL(colsum_stage1, dim3(cb, (unsigned)n), dim3(256), 0, st, x, (long long)rows, (long long)cols,
                      (long long)ldx, rpc, workspace);
   if (vitk::check_launch("vitk_colsum_f32/stage1")) return 1;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cols + RED_COLS - 1) / RED_COLS)), dim3(256), 0, st,
-                     workspace, n, (long long)cols, (long long)cols, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cols + RED_COLS - 1) / RED_COLS)),
+                     dim3(RED_COLS * RED_WAVES), 0, st, workspace, n, (long long)cols, (long long)cols,
+                     (long long)cols, out, (float *)nullptr);
   return vitk::check_launch("vitk_colsum_f32/stage2");
 }
 
@@ -368,11 +380,10 @@ int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const
   }
 #undef LNB
   if (vitk::check_launch("vitk_layernorm_bwd")) return 1;
-  const dim3 rg((unsigned)((D + RED_COLS - 1) / RED_COLS));
-  hipLaunchKernelGGL(reduce_partials_kernel, rg, dim3(256), 0, st, workspace, nblk, (long long)(2 * D), (long long)D,
-                     dgamma);
-  hipLaunchKernelGGL(reduce_partials_kernel, rg, dim3(256), 0, st, workspace + D, nblk, (long long)(2 * D),
-                     (long long)D, dbeta);
+  // a partial row is [dgamma(D) | dbeta(D)]: one launch reduces both
+  const dim3 rg((unsigned)((2 * D + RED_COLS - 1) / RED_COLS));
+  hipLaunchKernelGGL(reduce_partials_kernel, rg, dim3(RED_COLS * RED_WAVES), 0, st, workspace, nblk,
+                     (long long)(2 * D), (long long)(2 * D), (long long)D, dgamma, dbeta);
   return vitk::check_launch("vitk_layernorm_bwd/final");
 }
 
