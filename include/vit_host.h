@@ -83,10 +83,26 @@ int vith_predict(vith_model m, const float *x_dev, uint64_t B, int32_t *pred_dev
  * schedule over epochs * batches steps, Adam(L2), then evaluation on the test set in batches.
  * The data set is uploaded once and batches are gathered on the device.  history (may be NULL)
  * receives {train loss, train accuracy, test loss, test accuracy} per epoch.  Writes the
- * reference's vit_results.csv log into the current directory.  No augmentation is applied. */
+ * reference's vit_results.csv log into the current directory.  No augmentation (see below). */
 int vith_fit(vith_model m, const float *x, const float *y_onehot, uint64_t n, const float *x_test,
              const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
              float weight_decay, float warmup_frac, float *history);
+
+/* ---- DataAugmentation (include/utils/DataAugmentation.hpp:8-34, src/utils/DataAugmentation.cpp) --
+ * Config field for field (:11-19).  vith_augment = DataAugmentation(cfg).apply(batch) with the
+ * engine seeded by `seed` (the reference seeds it from random_device): x_dev, out_dev {B,C,H,W}.
+ * vith_fit_augmented = vith_fit with every training batch augmented as the reference's
+ * train_epoch does (src/model/Trainer.cpp:156-161, 198-201): one engine per epoch, seeded with
+ * augment_seed + epoch, drawing for the epoch's images in batch order; augment == NULL = vith_fit. */
+typedef struct vith_augment_config {
+  float rotation_prob, translate_prob, zoom_prob, rotation_factor, translate_factor, zoom_min, zoom_max;
+} vith_augment_config;
+int vith_augment(const vith_augment_config *cfg, uint32_t seed, const float *x_dev, uint64_t B, uint64_t C, uint64_t H,
+                 uint64_t W, float *out_dev);
+int vith_fit_augmented(vith_model m, const float *x, const float *y_onehot, uint64_t n, const float *x_test,
+                       const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
+                       float weight_decay, float warmup_frac, const vith_augment_config *augment, uint32_t augment_seed,
+                       float *history);
 
 /* ---- trainer: the per-batch body of Trainer::train_epoch (src/model/Trainer.cpp:201-227) ---- */
 vith_trainer vith_trainer_create(vith_model m, float beta1, float beta2, float eps, float weight_decay,

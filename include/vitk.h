@@ -201,6 +201,28 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
 int vitk_gather_rows_f32(const float *src, int64_t src_rows, const int32_t *index, int64_t rows, int64_t row_len,
                          float *dst, vitk_stream_t stream);
 
+/* ---- data augmentation (DataAugmentation::apply, src/utils/DataAugmentation.cpp:4-143) --------
+ * dst[b] = zoom(translate(rotate(src[index ? index[b] : b]))), each stage present only when its
+ * flag is set: the reference's three nearest-neighbour resamplings with zero fill, composed into
+ * one gather per output pixel (bit-identical to applying them one after another).  The random
+ * draws stay on the host (DataAugmentation in the host layer draws them in the reference's
+ * order); the kernel receives one record per image.  With `index` (device, B int32 values in
+ * [0, src_images)) the per-batch gather of shuffled samples is folded into the same pass.
+ *   rotate:    source = R(theta) (pixel - centre) + centre, cos/sin of the drawn angle (:42-64)
+ *   translate: source = pixel - (ty, tx), the drawn shifts truncated to int (:87-97)
+ *   zoom:      source = (pixel - centre) / zoom + centre (:127-128)
+ * src and dst are [.][C][H][W]; must not alias. */
+enum { VITK_AUG_ROTATE = 1, VITK_AUG_TRANSLATE = 2, VITK_AUG_ZOOM = 4 };
+typedef struct vitk_augment_params {
+  int32_t flags;
+  float cos_theta, sin_theta;
+  int32_t tx, ty;
+  float zoom;
+  int32_t reserved[2];
+} vitk_augment_params; /* 32 bytes */
+int vitk_augment_f32(const float *src, int64_t src_images, const int32_t *index, const vitk_augment_params *params,
+                     int64_t B, int32_t C, int32_t H, int32_t W, float *dst, vitk_stream_t stream);
+
 /* ---- patch extraction (src/layers/PatchEmbedding.cpp:31-52) -----------------------------------
  * img is [B][C][HW][HW]; patches is [B*Np][P*P*C], Np = (HW/P)^2.
  * VITK_PATCH_REFERENCE: what the reference CPU path does -- patch (ph,pw) is the P*P*C CONTIGUOUS

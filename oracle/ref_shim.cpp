@@ -29,6 +29,9 @@
 #define private public
 #include "model/VisionTransformer.hpp"
 #undef private
+#define private public
+#include "utils/DataAugmentation.hpp"  // private: the engine, to seed it (the class seeds it from random_device)
+#undef private
 #include "losses/CrossEntropy.hpp"
 #include "optimizers/Adam.hpp"
 #include "optimizers/Scheduler.hpp"
@@ -409,6 +412,19 @@ void vref_epoch_order(uint64_t n, int epoch, uint64_t *out) {
   std::mt19937 rng(static_cast<uint32_t>(epoch));
   std::shuffle(idx.begin(), idx.end(), rng);
   for (uint64_t i = 0; i < n; ++i) out[i] = idx[i];
+}
+
+// DataAugmentation::apply (src/utils/DataAugmentation.cpp:4-35) with the engine re-seeded.
+// cfg = the seven Config fields in declaration order.
+void vref_augment(const float *x, uint64_t B, uint64_t C, uint64_t H, uint64_t W, uint32_t seed, const float *cfg,
+                  float *out) {
+  DataAugmentation::Config c;
+  c.rotation_prob = cfg[0]; c.translate_prob = cfg[1]; c.zoom_prob = cfg[2];
+  c.rotation_factor = cfg[3]; c.translate_factor = cfg[4]; c.zoom_min = cfg[5]; c.zoom_max = cfg[6];
+  DataAugmentation aug(c);
+  aug.rng.seed(seed);
+  Tensor r = aug.apply(make({B, C, H, W}, x));
+  dump(r, out);
 }
 
 // first-max argmax over rows as app/test.cpp:103-112 / Trainer.cpp:33-42 define it.

@@ -516,6 +516,113 @@ static uint64_t emb_params(const vo_cfg *c) {
   return patch_dim(c) * c->embedding_dim + c->embedding_dim + c->embedding_dim + tokens(c) * c->embedding_dim;
 }
 
+/* ---------------------------------------------------------------- data augmentation ---------
+ * std::mt19937 (ISO C++ [rand.predef]: MT19937, 32-bit, seeded by the linear recurrence
+ * 1812433253) and GCC 11 libstdc++'s generate_canonical<float, 24> (bits/random.tcc): one 32-bit
+ * draw converted to float (round to nearest), divided by 2^32, clamped below 1;
+ * uniform_real_distribution<float>(a, b) = canonical * (b - a) + a. */
+typedef struct { uint32_t mt[624]; int idx; } vo_mt;
+static void vo_mt_seed(vo_mt *g, uint32_t seed) {
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+static uint32_t vo_mt_next(vo_mt *g) {
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+static float vo_uniform(vo_mt *g, float a, float b) {
+  float r = (float)vo_mt_next(g) / 4294967296.0f;
+  if (r >= 1.0f) r = nextafterf(1.0f, 0.0f);
+  return r * (b - a) + a;
+}
+
+/* one nearest-neighbour resampling stage over all channels: out(h, w) = in(sh, sw) or 0 */
+static void vo_aug_rotate(const float *in, float *out, uint64_t C, uint64_t H, uint64_t W, float angle) {
+  const float rad = (float)((double)angle * M_PI / 180.0f); /* :45, evaluated in double */
+  const float ct = cosf(rad), st = sinf(rad);
+  const float cx = W / 2.0f, cy = H / 2.0f;
+  for (uint64_t h = 0; h < H; ++h)
+    for (uint64_t w = 0; w < W; ++w) {
+      const float x = w - cx, y = h - cy;
+      const float sx = ct * x + st * y + cx;  /* :63-64 */
+      const float sy = -st * x + ct * y + cy;
+      const int ok = sx >= 0 && sx < W && sy >= 0 && sy < H;
+      for (uint64_t c = 0; c < C; ++c)
+        out[(c * H + h) * W + w] = ok ? in[(c * H + (uint64_t)sy) * W + (uint64_t)sx] : 0.0f;
+    }
+}
+static void vo_aug_translate(const float *in, float *out, uint64_t C, uint64_t H, uint64_t W, float tx, float ty) {
+  const int height = (int)H, width = (int)W;
+  for (int h = 0; h < height; ++h)
+    for (int w = 0; w < width; ++w) {
+      const int sh = h - (int)ty, sw = w - (int)tx; /* :96-97 */
+      const int ok = sh >= 0 && sh < height && sw >= 0 && sw < width;
+      for (uint64_t c = 0; c < C; ++c)
+        out[(c * H + (uint64_t)h) * W + (uint64_t)w] = ok ? in[(c * H + (uint64_t)sh) * W + (uint64_t)sw] : 0.0f;
+    }
+}
+static void vo_aug_zoom(const float *in, float *out, uint64_t C, uint64_t H, uint64_t W, float zoom) {
+  const float cx = W / 2.0f, cy = H / 2.0f;
+  for (uint64_t h = 0; h < H; ++h)
+    for (uint64_t w = 0; w < W; ++w) {
+      const float x = (w - cx) / zoom + cx; /* :127-128 */
+      const float y = (h - cy) / zoom + cy;
+      const int ok = x >= 0 && x < W && y >= 0 && y < H;
+      for (uint64_t c = 0; c < C; ++c)
+        out[(c * H + h) * W + w] = ok ? in[(c * H + (uint64_t)y) * W + (uint64_t)x] : 0.0f;
+    }
+}
+
+void vo_augment(const float *x, uint64_t B, uint64_t C, uint64_t H, uint64_t W, uint32_t seed, const float *cfg,
+                float *out, float *draws) {
+  const uint64_t sample = C * H * W;
+  vo_mt g;
+  vo_mt_seed(&g, seed);
+  float *a = (float *)malloc(sample * sizeof(float)), *b = (float *)malloc(sample * sizeof(float));
+  for (uint64_t i = 0; i < B; ++i) { /* :8-32 */
+    float rec[6] = {0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    int flags = 0;
+    memcpy(a, x + i * sample, sample * sizeof(float));
+    if (vo_uniform(&g, 0.0f, 1.0f) < cfg[0]) {
+      rec[1] = vo_uniform(&g, -cfg[3], cfg[3]);
+      vo_aug_rotate(a, b, C, H, W, rec[1]);
+      { float *t = a; a = b; b = t; }
+      flags |= 1;
+    }
+    if (vo_uniform(&g, 0.0f, 1.0f) < cfg[1]) {
+      rec[2] = vo_uniform(&g, -cfg[4], cfg[4]) * W; /* x first, then y (:87-88) */
+      rec[3] = vo_uniform(&g, -cfg[4], cfg[4]) * H;
+      vo_aug_translate(a, b, C, H, W, rec[2], rec[3]);
+      { float *t = a; a = b; b = t; }
+      flags |= 2;
+    }
+    if (vo_uniform(&g, 0.0f, 1.0f) < cfg[2]) {
+      rec[4] = vo_uniform(&g, cfg[5], cfg[6]);
+      vo_aug_zoom(a, b, C, H, W, rec[4]);
+      { float *t = a; a = b; b = t; }
+      flags |= 4;
+    }
+    rec[0] = (float)flags;
+    memcpy(out + i * sample, a, sample * sizeof(float));
+    if (draws) memcpy(draws + 6 * i, rec, sizeof rec);
+  }
+  free(a);
+  free(b);
+}
+
+
 uint64_t vo_param_count(const vo_cfg *c) {
   return emb_params(c) + c->num_layers * block_params(c->embedding_dim, c->mlp_hidden_dim) + 2 * c->embedding_dim +
          c->embedding_dim * c->num_classes + c->num_classes;

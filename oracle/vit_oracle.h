@@ -62,6 +62,17 @@ void vo_adam_update(float *p, const float *g, float *m, float *v, uint64_t n, fl
 float vo_cosine_warmup_lr(long long step, long long warmup, long long total, float lr_max);
 void vo_argmax_rows(const float *logits, uint64_t B, uint64_t K, int32_t *out);
 
+/* ---- data augmentation (src/utils/DataAugmentation.cpp:4-143) ----
+ * DataAugmentation(cfg).apply(x) with the engine seeded by `seed` instead of random_device.
+ * cfg = {rotation_prob, translate_prob, zoom_prob, rotation_factor, translate_factor, zoom_min,
+ * zoom_max} (include/utils/DataAugmentation.hpp:11-19).  x, out are [B][C][H][W].  draws
+ * (optional) receives 6 values per image: flags (1 rotate, 2 translate, 4 zoom), angle in degrees,
+ * tx, ty (before truncation), zoom, 0.  The random numbers restate std::mt19937 and GCC 11
+ * libstdc++'s uniform_real_distribution<float> / generate_canonical<float, 24> (one 32-bit draw
+ * per number); the image stages are applied one after another as the reference does. */
+void vo_augment(const float *x, uint64_t B, uint64_t C, uint64_t H, uint64_t W, uint32_t seed, const float *cfg,
+                float *out, float *draws);
+
 /* ---- whole model ---- */
 uint64_t vo_param_count(const vo_cfg *c);
 uint64_t vo_param_tensors(const vo_cfg *c);

@@ -185,8 +185,23 @@ def loss_curve():
     R.vref_destroy(s)
 
 
+def augment():
+    """DataAugmentation::apply of the reference with its engine re-seeded (vref_augment)."""
+    out = {}
+    for name in V.AUGMENT_CASES:
+        c = V.augment_case(name)
+        y = V.f32(c["B"], c["C"], c["H"], c["W"])
+        R.vref_augment(c["x"], c["B"], c["C"], c["H"], c["W"], c["seed"], c["cfg"], y)
+        out[name] = y
+    np.savez_compressed(os.path.join(G, "augment.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["augment"]:
+        augment()
+        sys.exit(0)
     ops()
+    augment()
     for name, (cfgd, B, seed, steps, full) in V.MODEL_CASES.items():
         model_case(name, cfgd, B, seed, steps, full)
     shipped_checkpoint()

@@ -469,6 +469,66 @@ def test_gather_rows_assembles_a_shuffled_batch(K):
     K.call("vitk_gather_rows_f32", dev(src), 50, dev(idx), 0, 37, out, K.stream())  # empty batch: no-op
 
 
+# ---------------------------------------- data augmentation (vitk_augment_f32)
+def aug_records(draws):
+    """Oracle draws (flags, angle, tx, ty, zoom, 0) -> the kernel's 32-byte records; cos/sin from
+    the C library's cosf/sinf, which is what std::cos(float) calls."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.cosf.restype = libm.sinf.restype = ctypes.c_float
+    libm.cosf.argtypes = libm.sinf.argtypes = [ctypes.c_float]
+    rec = np.zeros((len(draws), 8), np.int32)
+    f = rec.view(np.float32)
+    for i, (flags, angle, tx, ty, zoom, _) in enumerate(draws):
+        rad = np.float32(np.float64(np.float32(angle)) * np.pi / np.float64(np.float32(180.0)))
+        rec[i, 0] = int(flags)
+        f[i, 1], f[i, 2] = libm.cosf(float(rad)), libm.sinf(float(rad))
+        rec[i, 3], rec[i, 4] = int(tx), int(ty)  # truncation toward zero, as static_cast<int>
+        f[i, 5] = zoom
+    return rec
+
+
+@pytest.mark.parametrize("name", list(V.AUGMENT_CASES))
+def test_augment_kernel_is_the_three_stage_resampling_bit_for_bit(K, name):
+    """One gather per output pixel == rotation, translation and zoom applied one after another
+    (oracle: vo_augment, pinned to the reference's DataAugmentation); also folded with a batch
+    gather from a larger data set."""
+    O = V.oracle()
+    c = V.augment_case(name)
+    B, Cc, Hh, W = c["B"], c["C"], c["H"], c["W"]
+    want, draws = V.f32(B, Cc, Hh, W), V.f32(B, 6)
+    O.vo_augment(c["x"], B, Cc, Hh, W, c["seed"], c["cfg"], want, draws)
+    rec = dev(aug_records(draws).view(np.float32))
+    out = empty(B, Cc, Hh, W)
+    K.call("vitk_augment_f32", dev(c["x"]), B, None, rec, B, Cc, Hh, W, out, K.stream())
+    np.testing.assert_array_equal(host(out), want)
+    # folded gather: images of the batch are rows `idx` of a larger set
+    big = V.rng_normal(77, 3 * B, Cc, Hh, W)
+    idx = np.random.default_rng(5).permutation(3 * B)[:B].astype(np.int32)
+    O.vo_augment(np.ascontiguousarray(big[idx]), B, Cc, Hh, W, c["seed"], c["cfg"], want, draws)
+    K.call("vitk_augment_f32", dev(big), 3 * B, dev(idx), rec, B, Cc, Hh, W, out, K.stream())
+    np.testing.assert_array_equal(host(out), want)
+    K.call("vitk_augment_f32", dev(big), 3 * B, dev(idx), rec, 0, Cc, Hh, W, out, K.stream())  # empty batch
+
+
+def test_augment_kernel_full_size_properties(K):
+    """224x224x3 images, batch 256 (beyond what the oracle finishes quickly): no stage selected is
+    the identity; a pure integer translation is an exact shift with zero fill."""
+    B, Cc, S = 256, 3, 224
+    x = torch.randn(B, Cc, S, S, device="cuda")
+    rec = np.zeros((B, 8), np.int32)
+    rec.view(np.float32)[:, 5] = 1.0
+    out = torch.empty_like(x)
+    K.call("vitk_augment_f32", x, B, None, dev(rec.view(np.float32)), B, Cc, S, S, out, K.stream())
+    assert torch.equal(out, x)
+    rec[:, 0] = 2
+    rec[:, 3], rec[:, 4] = 5, -7  # tx, ty
+    K.call("vitk_augment_f32", x, B, None, dev(rec.view(np.float32)), B, Cc, S, S, out, K.stream())
+    want = torch.zeros_like(x)
+    want[:, :, :S - 7, 5:] = x[:, :, 7:, :S - 5]  # out(h, w) = x(h + 7, w - 5)
+    assert torch.equal(out, want)
+
+
 # ---------------------------------------- fused attention (vitk_sdpa_fwd / vitk_sdpa_bwd)
 def sdpa_numpy(q, k, v, do, scale):
     """float64 attention per (batch, head): q, k, v, do are [B][H][N][dh]."""

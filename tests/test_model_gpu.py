@@ -511,12 +511,30 @@ def test_cuda_tree_checkpoint_loads_with_conv_patch_projection(H, tmp_path):
     np.testing.assert_array_equal(host_np(m2.forward(dev(x), training=False)), got)
 
 
+# ------------------------------------------------------------------ DataAugmentation (host class)
+@pytest.mark.parametrize("name", list(V.AUGMENT_CASES))
+def test_data_augmentation_apply_matches_the_reference_stream(H, name):
+    """DataAugmentation(cfg, seed).apply(batch): host-side draws in the reference's order +
+    device resampling, bit for bit against the oracle (itself pinned to the reference's class
+    with the same engine seed, tests/golden/augment.npz)."""
+    O = V.oracle()
+    c = V.augment_case(name)
+    want = V.f32(c["B"], c["C"], c["H"], c["W"])
+    O.vo_augment(c["x"], c["B"], c["C"], c["H"], c["W"], c["seed"], c["cfg"], want, None)
+    got = H.augment(H.AugmentConfig.make(*[float(v) for v in c["cfg"]]), c["seed"], torch.from_numpy(c["x"]).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(want, V.golden("augment.npz")[name])
+
 # ------------------------------------------------------------------ the whole Trainer::train loop
-def test_fit_reproduces_the_reference_epoch_loop(H, tmp_path, monkeypatch):
+@pytest.mark.parametrize("augmented", [False, True])
+def test_fit_reproduces_the_reference_epoch_loop(H, tmp_path, monkeypatch, augmented):
     """Trainer::train through the C-ABI (data set resident on the device, batches gathered there)
     against the same loop spelled out in Python around the CPU oracle: per-epoch mt19937(epoch)
     shuffle, ragged last batch, cosine/warm-up schedule over all steps, Adam(L2), batched
-    evaluation (src/model/Trainer.cpp:60-271, without the reference's random augmentation)."""
+    evaluation (src/model/Trainer.cpp:60-271).  augmented: every training batch goes through
+    DataAugmentation with the reference's probabilities (:156-161, 198-201), one engine per epoch
+    whose stream runs through the epoch's batches -- seeded here, random_device there."""
     monkeypatch.chdir(tmp_path)  # the trainer writes the reference's vit_results.csv log here
     O = V.oracle()
     cfgd = V.TINY
@@ -531,7 +549,9 @@ def test_fit_reproduces_the_reference_epoch_loop(H, tmp_path, monkeypatch):
 
     m = H.Model(hcfg(H, cfgd))
     m.set_params(prm)
-    hist = m.fit(x, y, xt, yt, E, BS, lr_init, wd, wf)
+    aug_seed, aug_cfg = 1234, np.array([0.5, 0.5, 0.5, 10.0, 0.1, 0.9, 1.1], np.float32)
+    hist = m.fit(x, y, xt, yt, E, BS, lr_init, wd, wf, augment=H.AugmentConfig.make() if augmented else None,
+                 augment_seed=aug_seed)
 
     s = O.vo_session_create(ocfg, 0.9, 0.999, 1e-8, wd)
     O.vo_session_set_params(s, prm)
@@ -539,10 +559,14 @@ def test_fit_reproduces_the_reference_epoch_loop(H, tmp_path, monkeypatch):
     total, step, want = nb * E, 0, []
     for epoch in range(E):
         order = H.epoch_order(n, epoch)
+        x_epoch = np.ascontiguousarray(x[order])
+        if augmented:  # the engine's stream runs through the epoch's images in batch order
+            src = x_epoch.copy()
+            O.vo_augment(src, n, 1, 28, 28, aug_seed + epoch, aug_cfg, x_epoch, None)
         tl = ta = 0.0
         for b in range(nb):
             idx = order[b * BS:(b + 1) * BS]
-            xb, yb = np.ascontiguousarray(x[idx]), np.ascontiguousarray(y[idx])
+            xb, yb = np.ascontiguousarray(x_epoch[b * BS:(b + 1) * BS]), np.ascontiguousarray(y[idx])
             logits = V.f32(len(idx), K)
             lr = H.cosine_warmup_lr(step, int(wf * total), total, lr_init)
             tl += O.vo_session_train_step(s, xb, yb, len(idx), lr, logits, None)

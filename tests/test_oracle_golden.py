@@ -163,3 +163,12 @@ def test_loss_curve_golden():
         assert abs(lo - g["losses"][t]) <= 1e-4 * abs(g["losses"][t]), (t, lo, g["losses"][t])
     O.vo_session_destroy(s)
     assert g["losses"][-1] < g["losses"][0]
+
+
+@pytest.mark.parametrize("name", list(V.AUGMENT_CASES))
+def test_augmentation_golden(name):
+    """tests/golden/augment.npz: the reference's DataAugmentation::apply with a seeded engine."""
+    c = V.augment_case(name)
+    o = V.f32(c["B"], c["C"], c["H"], c["W"])
+    O.vo_augment(c["x"], c["B"], c["C"], c["H"], c["W"], c["seed"], c["cfg"], o, None)
+    np.testing.assert_array_equal(o, V.golden("augment.npz")[name])

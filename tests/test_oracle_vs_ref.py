@@ -230,3 +230,30 @@ def test_train_steps_match_reference():
     O.vo_session_get_params(o, p1); R.vref_get_params(s, p2)
     assert V.max_relerr(p1, p2) <= 1e-5
     O.vo_session_destroy(o); R.vref_destroy(s)
+
+
+@pytest.mark.parametrize("name", list(V.AUGMENT_CASES))
+def test_augmentation_matches_reference_bit_for_bit(name):
+    """Random draws (mt19937 + libstdc++ uniform_real_distribution<float>) and the three
+    resampling stages of src/utils/DataAugmentation.cpp, against the reference's own class with
+    its engine re-seeded."""
+    c = V.augment_case(name)
+    o, r = V.f32(c["B"], c["C"], c["H"], c["W"]), V.f32(c["B"], c["C"], c["H"], c["W"])
+    draws = V.f32(c["B"], 6)
+    O.vo_augment(c["x"], c["B"], c["C"], c["H"], c["W"], c["seed"], c["cfg"], o, draws)
+    R.vref_augment(c["x"], c["B"], c["C"], c["H"], c["W"], c["seed"], c["cfg"], r)
+    same(o, r)
+    if name == "all_stages_rgb":
+        assert (draws[:, 0] == 7).all() and (o != c["x"]).any()
+    if name == "none":
+        assert (draws[:, 0] == 0).all()
+        same(o, c["x"])
+
+
+def test_augmentation_many_seeds():
+    c = V.augment_case("all_stages_rgb")
+    for seed in range(40):
+        o, r = V.f32(*c["x"].shape), V.f32(*c["x"].shape)
+        O.vo_augment(c["x"], c["B"], c["C"], c["H"], c["W"], seed, c["cfg"], o, None)
+        R.vref_augment(c["x"], c["B"], c["C"], c["H"], c["W"], seed, c["cfg"], r)
+        same(o, r)

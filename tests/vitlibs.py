@@ -123,6 +123,7 @@ _ORACLE_SIGS = {
     "vo_session_get_params": "Pp>v",
     "vo_session_set_class_weights": "Ppu>v",
     "vo_session_train_step": "Pppufpp>f",
+    "vo_augment": "puuuuippp>v",
 }
 
 _REF_SIGS = {
@@ -161,6 +162,7 @@ _REF_SIGS = {
     "vref_cosine_warmup_lr": "lllf>f",
     "vref_epoch_order": "uip>v",
     "vref_argmax": "puup>v",
+    "vref_augment": "puuuuipp>v",
 }
 
 _cache = {}
@@ -396,6 +398,21 @@ def loss_curve_inputs():
         ys.append(onehot(lab, 10))
     return dict(cfg=cfg, B=B, steps=steps, prm=init_params(cfg, seed, noise_bias=False),
                 w=np.full(10, 0.1, np.float32), xs=xs, ys=ys)
+
+
+# name -> (B, C, H, W, engine seed, DataAugmentation::Config fields in declaration order)
+AUGMENT_CASES = {
+    "defaults_mnist": (16, 1, 28, 28, 7, (0.5, 0.5, 0.5, 10.0, 0.1, 0.9, 1.1)),      # Trainer.cpp:157-161
+    "all_stages_rgb": (6, 3, 28, 28, 11, (1.0, 1.0, 1.0, 30.0, 0.25, 0.7, 1.4)),
+    "rectangular": (5, 2, 20, 33, 3, (0.8, 0.8, 0.8, 45.0, 0.3, 0.5, 2.0)),
+    "rotate_only": (4, 1, 17, 17, 5, (1.0, 0.0, 0.0, 180.0, 0.1, 0.9, 1.1)),
+    "none": (3, 1, 8, 8, 9, (0.0, 0.0, 0.0, 10.0, 0.1, 0.9, 1.1)),
+}
+
+
+def augment_case(name):
+    B, Cc, H, W, seed, cfg = AUGMENT_CASES[name]
+    return dict(B=B, C=Cc, H=H, W=W, seed=seed, cfg=np.array(cfg, np.float32), x=rng_normal(900 + seed, B, Cc, H, W))
 
 
 def golden(name):

@@ -39,6 +39,53 @@ __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t 
   }
 }
 
+// Rotation, translation and zoom of one image are three successive nearest-neighbour resamplings
+// with zero fill (src/utils/DataAugmentation.cpp:37-143 of the reference).  Each one maps an
+// output pixel to at most one source pixel, so the chain is evaluated backwards per output pixel
+// -- zoom, then translation, then rotation -- and the result is one gather from the source image
+// (or zero as soon as any stage falls outside).  The coordinate arithmetic repeats the
+// reference's float operations one by one (no contraction into fused multiply-adds), so the
+// selected source pixel is the same.
+__global__ void augment_kernel(const float *__restrict__ src, const int32_t *__restrict__ index,
+                               const vitk_augment_params *__restrict__ prm, long long B, int C, int H, int W,
+                               float *__restrict__ dst) {
+#pragma clang fp contract(off)
+  const long long plane = (long long)H * W, total = B * plane;
+  const float fw = (float)W, fh = (float)H, cx = fw / 2.0f, cy = fh / 2.0f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / plane;
+    const int h = (int)((i % plane) / W), w = (int)(i % W);
+    const vitk_augment_params P = prm[b];
+    bool inside = true;
+    int ch = h, cw = w;
+    if (P.flags & VITK_AUG_ZOOM) {  // :114-143
+      const float x = ((float)cw - cx) / P.zoom + cx;
+      const float y = ((float)ch - cy) / P.zoom + cy;
+      inside = x >= 0.f && x < fw && y >= 0.f && y < fh;
+      cw = (int)x;
+      ch = (int)y;
+    }
+    if (inside && (P.flags & VITK_AUG_TRANSLATE)) {  // :82-112
+      ch -= P.ty;
+      cw -= P.tx;
+      inside = ch >= 0 && ch < H && cw >= 0 && cw < W;
+    }
+    if (inside && (P.flags & VITK_AUG_ROTATE)) {  // :37-80
+      const float x = (float)cw - cx, y = (float)ch - cy;
+      const float sx = P.cos_theta * x + P.sin_theta * y + cx;
+      const float sy = -P.sin_theta * x + P.cos_theta * y + cy;
+      inside = sx >= 0.f && sx < fw && sy >= 0.f && sy < fh;
+      cw = (int)sx;
+      ch = (int)sy;
+    }
+    const long long sb = index ? (long long)index[b] : b;
+    const float *s = src + sb * C * plane + (long long)ch * W + cw;
+    float *d = dst + b * C * plane + (long long)h * W + w;
+    for (int c = 0; c < C; ++c) d[c * plane] = inside ? s[c * plane] : 0.f;
+  }
+}
+
 __global__ void embed_assemble_kernel(const float *__restrict__ proj, const float *__restrict__ cls,
                                       const float *__restrict__ pos, int B, int Np, int D, float *__restrict__ out) {
   const int N = Np + 1;
@@ -146,6 +193,17 @@ int vitk_gather_rows_f32(const float *src, int64_t src_rows, const int32_t *inde
   hipLaunchKernelGGL(gather_rows_kernel, dim3(vitk::grid_for(rows * row_len, TPB)), dim3(TPB), 0,
                      vitk::as_stream(stream), src, index, (long long)rows, (long long)row_len, dst);
   return vitk::check_launch("vitk_gather_rows_f32");
+}
+
+int vitk_augment_f32(const float *src, int64_t src_images, const int32_t *index, const vitk_augment_params *params,
+                     int64_t B, int32_t C, int32_t H, int32_t W, float *dst, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && src_images >= 0, "vitk_augment_f32: bad shape");
+  if (B == 0) return 0;
+  VITK_REQUIRE(src && params && dst && src != dst, "vitk_augment_f32: null pointer or in-place call");
+  VITK_REQUIRE(index != nullptr || src_images >= B, "vitk_augment_f32: source holds fewer images than the batch");
+  hipLaunchKernelGGL(augment_kernel, dim3(vitk::grid_for(B * H * W, TPB)), dim3(TPB), 0, vitk::as_stream(stream), src,
+                     index, params, (long long)B, C, H, W, dst);
+  return vitk::check_launch("vitk_augment_f32");
 }
 
 int vitk_cls_gather(const float *x, int32_t B, int32_t N, int32_t D, float *cls_rows, vitk_stream_t stream) {

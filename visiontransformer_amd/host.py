@@ -72,6 +72,9 @@ SIGNATURES = {
     "vith_num_stages": (_u64, [_p]),
     "vith_step_backward_stage": (_int, [_p, _u64]),
     "vith_fit": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float, _p]),
+    "vith_fit_augmented": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float, _p,
+                                  C.c_uint32, _p]),
+    "vith_augment": (_int, [_p, C.c_uint32, _p, _u64, _u64, _u64, _u64, _p]),
     "vith_trainer_save_state": (_int, [_p, C.c_char_p]),
     "vith_trainer_load_state": (_int, [_p, C.c_char_p]),
     "vith_stage_grad_range": (_int, [_p, _u64, _pu, _pu]),
@@ -144,6 +147,27 @@ def cosine_warmup_lr(step, warmup, total, lr_max):
     return dll().vith_cosine_warmup_lr(step, warmup, total, lr_max)
 
 
+class AugmentConfig(C.Structure):
+    """DataAugmentation::Config (include/utils/DataAugmentation.hpp:11-19 of the reference)."""
+    _fields_ = [(n, C.c_float) for n in ("rotation_prob", "translate_prob", "zoom_prob", "rotation_factor",
+                                         "translate_factor", "zoom_min", "zoom_max")]
+
+    @classmethod
+    def make(cls, rotation_prob=0.5, translate_prob=0.5, zoom_prob=0.5, rotation_factor=10.0, translate_factor=0.1,
+             zoom_min=0.9, zoom_max=1.1):
+        return cls(rotation_prob, translate_prob, zoom_prob, rotation_factor, translate_factor, zoom_min, zoom_max)
+
+
+def augment(cfg, seed, x, out=None):
+    """DataAugmentation(cfg).apply(x) with the engine seeded by `seed`; x is a {B,C,H,W} CUDA tensor."""
+    import torch
+    if out is None:
+        out = torch.empty_like(x)
+    B, Cc, Hh, W = x.shape
+    _check(dll().vith_augment(C.byref(cfg), seed, x.data_ptr(), B, Cc, Hh, W, out.data_ptr()))
+    return out
+
+
 def epoch_order(n, epoch):
     out = np.zeros(n, dtype=np.uint64)
     _check(dll().vith_epoch_order(n, epoch, out.ctypes.data))
@@ -207,12 +231,16 @@ class Model:
     def grads_device(self):
         return dll().vith_grads_device(self.h)
 
-    def fit(self, x, y, x_test, y_test, epochs, batch_size, lr_init=3e-4, weight_decay=1e-4, warmup_frac=0.1):
-        """Trainer::train on host numpy arrays; returns [epochs][4] = train loss/acc, test loss/acc."""
+    def fit(self, x, y, x_test, y_test, epochs, batch_size, lr_init=3e-4, weight_decay=1e-4, warmup_frac=0.1,
+            augment=None, augment_seed=0):
+        """Trainer::train on host numpy arrays; returns [epochs][4] = train loss/acc, test loss/acc.
+        augment: an AugmentConfig to augment every training batch (engine seed augment_seed + epoch)."""
         x, y, x_test, y_test = (np.ascontiguousarray(a, np.float32) for a in (x, y, x_test, y_test))
         hist = np.zeros((epochs, 4), np.float32)
-        _check(dll().vith_fit(self.h, x.ctypes.data, y.ctypes.data, x.shape[0], x_test.ctypes.data, y_test.ctypes.data,
-                              x_test.shape[0], epochs, batch_size, lr_init, weight_decay, warmup_frac, hist.ctypes.data))
+        _check(dll().vith_fit_augmented(self.h, x.ctypes.data, y.ctypes.data, x.shape[0], x_test.ctypes.data,
+                                        y_test.ctypes.data, x_test.shape[0], epochs, batch_size, lr_init, weight_decay,
+                                        warmup_frac, C.byref(augment) if augment is not None else None, augment_seed,
+                                        hist.ctypes.data))
         return hist
 
     def save_weights(self, path):

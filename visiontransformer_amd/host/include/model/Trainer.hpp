@@ -1,7 +1,8 @@
 // Trainer + TrainerConfig (reference: include/model/Trainer.hpp, src/model/Trainer.cpp): epoch loop
 // with the per-epoch mt19937(epoch) shuffle, cosine/warm-up schedule, Adam(L2), CSV log.  The
-// reference's CPU-side random augmentation (hard-wired probabilities, random_device seeded) is not
-// applied; everything else in the per-batch body is the same sequence of calls.
+// reference augments every training batch with hard-wired probabilities from a random_device
+// seeded engine (src/model/Trainer.cpp:156-161, 198-201); here that is TrainerConfig::augment,
+// off by default, with a seed so that runs can be repeated.
 #ifndef TRAINER_HPP
 #define TRAINER_HPP
 
@@ -13,6 +14,7 @@
 #include "losses/CrossEntropy.hpp"
 #include "model/VisionTransformer.hpp"
 #include "optimizers/Adam.hpp"
+#include "utils/DataAugmentation.hpp"
 #include "utils/DataReader.hpp"
 #include "utils/Logger.hpp"
 
@@ -32,6 +34,12 @@ struct TrainerConfig {
   // state_path + ".weights".  start_epoch: first epoch to run when resuming from such a state.
   std::string state_path;
   int start_epoch = 0;
+  // augment: apply DataAugmentation (probabilities 0.5 / 0.5 / 0.5 and the Config defaults, as
+  // src/model/Trainer.cpp:157-161) to every training batch, on the device, folded into the batch
+  // gather.  One engine per epoch, as in the reference, seeded with augment_seed + epoch.
+  bool augment = false;
+  uint32_t augment_seed = 0;
+  DataAugmentation::Config augment_config;
 };
 
 class Trainer {

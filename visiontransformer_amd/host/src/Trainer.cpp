@@ -131,15 +131,34 @@ std::pair<float, float> Trainer::train_epoch(const Tensor &X_train, const Tensor
   Tensor order_dev = Tensor::deviceEmpty({n});  // n int32 values in a 4-byte-per-element block
   vit::copy_to_device(order_dev.deviceDataOverwrite(), reinterpret_cast<const float *>(order32.data()), n);
   const int32_t *order = reinterpret_cast<const int32_t *>(order_dev.deviceData());
+  // Augmentation (src/model/Trainer.cpp:156-161, 198-199): one engine per epoch whose draws run
+  // through the epoch's images in batch order, so all of them are made up front and go up as one
+  // array; the resampling is folded into the batch gather.
+  Tensor aug_dev;
+  const vitk_augment_params *aug = nullptr;
+  if (config.augment) {
+    DataAugmentation augmentor(config.augment_config, config.augment_seed + static_cast<uint32_t>(epoch));
+    std::vector<vitk_augment_params> draws;
+    augmentor.draw(n, shape[2], shape[3], draws);
+    constexpr size_t kWords = sizeof(vitk_augment_params) / sizeof(float);
+    aug_dev = Tensor::deviceEmpty({n * kWords});
+    vit::copy_to_device(aug_dev.deviceDataOverwrite(), reinterpret_cast<const float *>(draws.data()), n * kWords);
+    aug = reinterpret_cast<const vitk_augment_params *>(aug_dev.deviceData());
+  }
   for (size_t i = 0; i < num_batches; ++i) {
     const size_t first = i * config.batch_size;
     const size_t count = std::min(config.batch_size, n - first);
     if (count == 0) continue;
     Tensor X_batch = Tensor::deviceEmpty({count, shape[1], shape[2], shape[3]});
     Tensor y_batch = Tensor::deviceEmpty({count, K});
-    vit::check(vitk_gather_rows_f32(xsrc, (int64_t)n, order + first, (int64_t)count, (int64_t)sample,
-                                    X_batch.deviceDataOverwrite(), vit::stream()),
-               "vitk_gather_rows_f32");
+    if (aug != nullptr)
+      vit::check(vitk_augment_f32(xsrc, (int64_t)n, order + first, aug + first, (int64_t)count, (int32_t)shape[1],
+                                  (int32_t)shape[2], (int32_t)shape[3], X_batch.deviceDataOverwrite(), vit::stream()),
+                 "vitk_augment_f32");
+    else
+      vit::check(vitk_gather_rows_f32(xsrc, (int64_t)n, order + first, (int64_t)count, (int64_t)sample,
+                                      X_batch.deviceDataOverwrite(), vit::stream()),
+                 "vitk_gather_rows_f32");
     vit::check(vitk_gather_rows_f32(ysrc, (int64_t)n, order + first, (int64_t)count, (int64_t)K,
                                     y_batch.deviceDataOverwrite(), vit::stream()),
                "vitk_gather_rows_f32");

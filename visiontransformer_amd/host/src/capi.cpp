@@ -249,9 +249,37 @@ int vith_step_update(vith_trainer t, float lr, float grad_scale) {
     s->adam.update(p, g);
   });
 }
+static DataAugmentation::Config to_aug(const vith_augment_config *a) {
+  DataAugmentation::Config c;
+  c.rotation_prob = a->rotation_prob;
+  c.translate_prob = a->translate_prob;
+  c.zoom_prob = a->zoom_prob;
+  c.rotation_factor = a->rotation_factor;
+  c.translate_factor = a->translate_factor;
+  c.zoom_min = a->zoom_min;
+  c.zoom_max = a->zoom_max;
+  return c;
+}
+int vith_augment(const vith_augment_config *cfg, uint32_t seed, const float *x_dev, uint64_t B, uint64_t C, uint64_t H,
+                 uint64_t W, float *out_dev) {
+  return guard([&] {
+    if (!cfg || !x_dev || !out_dev) throw std::invalid_argument("vith_augment: null pointer");
+    DataAugmentation augmentor(to_aug(cfg), seed);
+    Tensor x = Tensor::wrapDevice(const_cast<float *>(x_dev), {(size_t)B, (size_t)C, (size_t)H, (size_t)W});
+    Tensor y = augmentor.apply(x);
+    vit::copy_on_device(out_dev, y.deviceData(), (size_t)(B * C * H * W));
+  });
+}
 int vith_fit(vith_model m, const float *x, const float *y, uint64_t n, const float *x_test, const float *y_test,
              uint64_t n_test, int epochs, uint64_t batch_size, float lr_init, float weight_decay, float warmup_frac,
              float *history) {
+  return vith_fit_augmented(m, x, y, n, x_test, y_test, n_test, epochs, batch_size, lr_init, weight_decay, warmup_frac,
+                            nullptr, 0, history);
+}
+int vith_fit_augmented(vith_model m, const float *x, const float *y, uint64_t n, const float *x_test,
+                       const float *y_test, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
+                       float weight_decay, float warmup_frac, const vith_augment_config *augment, uint32_t augment_seed,
+                       float *history) {
   return guard([&] {
     VisionTransformer &v = M(m)->vit;
     const ViTConfig &c = v.getConfig();
@@ -268,6 +296,11 @@ int vith_fit(vith_model m, const float *x, const float *y, uint64_t n, const flo
     tc.learning_rate = lr_init;
     tc.weight_decay = weight_decay;
     tc.warmup_frac = warmup_frac;
+    if (augment) {
+      tc.augment = true;
+      tc.augment_seed = augment_seed;
+      tc.augment_config = to_aug(augment);
+    }
     Trainer trainer(v, tc);
     trainer.setQuiet(true);
     trainer.train(wrap(x, y, n), wrap(x_test, y_test, n_test));
