@@ -460,6 +460,42 @@ def test_gemm_tail_round_split_keeps_every_epilogue_operand_aligned(K, ta):
     close(host(c), gelu + res, 1e-5)
 
 
+@pytest.mark.parametrize("ta,rem", [(0, 64), (0, 37), (1, 32), (0, 1)])
+def test_gemm_ragged_last_tile_row_on_the_unguarded_path(K, ta, rem):
+    """M = 5 x 128 + rem rows (a batch whose token count is not a tile multiple) with everything
+    else aligned: the last tile row reads zeros beyond the operand's extent and stores only its
+    valid rows; bias, pre-activation output, GELU and residual must follow the rows."""
+    M, N, Kd = 5 * 128 + rem, 256, 48
+    a = V.rng_normal(17, *((Kd, M) if ta else (M, Kd)))
+    b, bias, res = V.rng_normal(18, Kd, N), V.rng_normal(19, N), V.rng_normal(20, M, N)
+    c, aux = empty(M, N), empty(M, N)
+    K.gemm(dev(a), dev(b), c, M, N, Kd, trans_a=bool(ta), bias=dev(bias), act=K.ACT_GELU_FWD, aux=aux,
+           residual=dev(res))
+    pre = ref_gemm(a, b, ta, 0) + bias
+    close(host(aux), pre, 1e-5)
+    gelu = 0.5 * pre * (1.0 + np.tanh(0.7978845608028654 * (pre + 0.044715 * pre ** 3)))
+    close(host(c), gelu + res, 1e-5)
+    plain = empty(M, N)
+    K.gemm(dev(a), dev(b), plain, M, N, Kd, trans_a=bool(ta))
+    close(host(plain), ref_gemm(a, b, ta, 0), 1e-5)
+
+@pytest.mark.parametrize("Kd,split", [(16 * 7 + 5, 1), (4096 + 37, 0), (16 * 40 + 1, 3)])
+def test_gemm_ragged_contraction_of_a_weight_gradient(K, Kd, split):
+    """dW = X^T dY with a token count that is not a multiple of the slab depth (batch 100 x 197):
+    the k beyond the end read as zeros through the descriptor extents.  The operands sit at the end
+    of buffers whose remainder is NaN, so an unclipped read would poison the result."""
+    M, N = 256, 384
+    x, dy = V.rng_normal(31, Kd, M), V.rng_normal(32, Kd, N)
+    pad = 64 * max(M, N)
+    bx = torch.full((Kd * M + pad,), float("nan"), device="cuda")
+    bdy = torch.full((Kd * N + pad,), float("nan"), device="cuda")
+    bx[:Kd * M] = dev(x).reshape(-1)
+    bdy[:Kd * N] = dev(dy).reshape(-1)
+    dw, bias = empty(M, N), empty(N)
+    K.gemm(bx, bdy, dw, M, N, Kd, trans_a=True, split_k=split, colsum_b=bias)
+    close(host(dw), x.astype(np.float64).T @ dy.astype(np.float64), 1e-5)
+    close(host(bias), dy.astype(np.float64).sum(0), 1e-5)
+
 def test_gather_rows_assembles_a_shuffled_batch(K):
     src = V.rng_normal(3, 50, 37)
     idx = np.random.default_rng(4).permutation(50)[:21].astype(np.int32)

@@ -125,6 +125,10 @@ struct KContig {
   }
   __device__ static long long origin(long long ld, int row0, int k0) { return (long long)row0 * ld + k0; }
   __device__ static long long slab_bytes(long long) { return BK * 4; }
+  // bytes from the origin to the end of the operand: `rows` rows of which the last holds `ks` k
+  __device__ static unsigned extent_bytes(long long ld, int rows, int ks) {
+    return (unsigned)(((long long)(rows - 1) * ld + ks) * 4);
+  }
   __device__ static void store(float *__restrict__ s, const f32x4 (&reg)[NL]) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
@@ -176,6 +180,9 @@ struct MnContig {
   }
   __device__ static long long origin(long long ld, int row0, int k0) { return (long long)k0 * ld + row0; }
   __device__ static long long slab_bytes(long long ld) { return BK * ld * 4; }
+  __device__ static unsigned extent_bytes(long long ld, int rows, int ks) {
+    return (unsigned)(((long long)(ks - 1) * ld + rows) * 4);
+  }
   __device__ static void store(float *__restrict__ s, const f32x4 (&reg)[NL]) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
@@ -197,9 +204,9 @@ struct Operand<false, ROWS> : MnContig<ROWS> {};
 // not for its global prefetch loads, which __syncthreads() would also drain).
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// FULL: every tile and every K slab is complete and all operands allow 16-byte accesses, so the
-// loop and the epilogue carry no bounds checks at all (true for every large contraction of
-// ViT-Ti/S/B).
+// FULL: all operands allow 16-byte accesses and N is made of whole tiles; the loop carries no
+// bounds checks at all (a ragged last tile row, and a ragged contraction of a weight-gradient
+// product, are cut off by the extents of the buffer descriptors), the epilogue only a row mask.
 template <int TILE, bool TA, bool TB, bool FULL>
 __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Params p) {
   using OpA = Operand<!TA, TILE>;  // A is k-contiguous when not transposed
@@ -267,8 +274,13 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   int so_a = 0, so_b = 0;
   const int step_a = (int)OpA::slab_bytes(p.lda), step_b = (int)OpB::slab_bytes(p.ldb);
   if constexpr (FULL) {
-    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + OpA::origin(p.lda, m0, kbeg)), 0, -1, 0x00020000);
-    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + OpB::origin(p.ldb, n0, kbeg)), 0, -1, 0x00020000);
+    // The descriptors end exactly where the operand does (counted from the tile origin), so rows
+    // of a ragged last tile and -- where k is the slow index of both operands -- the k beyond a
+    // ragged contraction read as zeros without any bounds check in the loop.
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + OpA::origin(p.lda, m0, kbeg)), 0,
+                                               (int)OpA::extent_bytes(p.lda, p.M - m0, p.K - kbeg), 0x00020000);
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + OpB::origin(p.ldb, n0, kbeg)), 0,
+                                               (int)OpB::extent_bytes(p.ldb, p.N - n0, p.K - kbeg), 0x00020000);
     OpA::lane_offsets(p.lda, offa);
     OpB::lane_offsets(p.ldb, offb);
   }
@@ -432,10 +444,12 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
       const unsigned lane_w = (unsigned)((l16 * (long long)p.N + 4 * g16) * 4);
 #pragma unroll
-      for (int i = 0; i < NTX; ++i)
+      for (int i = 0; i < NTX; ++i) {
+        if (row_w + i * 16 + l16 >= p.M) continue;  // ragged last tile row
 #pragma unroll
         for (int j = 0; j < NTX; ++j)
           *reinterpret_cast<f32x4 *>(W + ((long long)(i * 16) * p.N + j * 16) * 4 + lane_w) = acc[i][j];
+      }
     } else {
       char *C = reinterpret_cast<char *>(p.C + bo * p.sc_o + bi * p.sc_i + (long long)row_w * p.ldc + col_w);
       const char *R =
@@ -446,8 +460,10 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       const unsigned lane_x = (unsigned)((l16 * p.ldaux + 4 * g16) * 4);
 #pragma unroll
       for (int i = 0; i < NTX; ++i) {
+        const bool row_ok = row_w + i * 16 + l16 < p.M;  // false only in a ragged last tile row
 #pragma unroll
         for (int j = 0; j < NTX; ++j) {
+          if (!row_ok) break;
           const int col = col_w + j * 16 + 4 * g16;
           f32x4 *cp = reinterpret_cast<f32x4 *>(C + ((long long)(i * 16) * p.ldc + j * 16) * 4 + lane_c);
           f32x4 *xp = reinterpret_cast<f32x4 *>(X + ((long long)(i * 16) * p.ldaux + j * 16) * 4 + lane_x);
@@ -690,7 +706,7 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
     const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
     const int head_rows = (int)(tiles / slots * slots / pl.tiles_n);  // tile rows inside the full rounds
     const int tail_rows = pl.tiles_m - head_rows;
-    if (head_rows > 0 && tail_rows > 0 && tail_rows * pl.tiles_n <= tail_max && a->M % 128 == 0) {
+    if (head_rows > 0 && tail_rows > 0 && tail_rows * pl.tiles_n <= tail_max) {
       const int m_head = head_rows * 128;
       vitk_gemm_args head = *a, tail = *a;
       head.M = m_head;
@@ -740,8 +756,9 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   hipStream_t st = vitk::as_stream(stream);
   dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)(pl.batch * pl.split_k), 1);
   // every K chunk starts and ends on a slab boundary when K and the chunk are multiples of BK
-  const bool full = p.vec_a && p.vec_b && a->M % pl.tile == 0 && a->N % pl.tile == 0 && a->K > 0 &&
-                    a->K % BK == 0 && pl.k_chunk % BK == 0 && a->lda < (1 << 21) && a->ldb < (1 << 21) &&
+  // ragged M is masked in the epilogue; a ragged K only where k is the slow index of both operands
+  const bool full = p.vec_a && p.vec_b && a->N % pl.tile == 0 && a->K > 0 &&
+                    (a->K % BK == 0 || (a->trans_a && !a->trans_b)) && pl.k_chunk % BK == 0 && a->lda < (1 << 21) && a->ldb < (1 << 21) &&
                     (!a->trans_a || (long long)(a->K + BK) * a->lda * 4 < (1ll << 31)) &&
                     (a->trans_b || (long long)(a->K + BK) * a->ldb * 4 < (1ll << 31)) &&
                     a->ldc < (1 << 21) && a->ldr < (1 << 21) && a->ldaux < (1 << 21) &&
