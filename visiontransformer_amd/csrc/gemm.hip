@@ -618,6 +618,26 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
   if (s < 1) s = 1;
   pl->split_k = s;
   pl->k_chunk = chunk;
+  // Few 128-wide tiles: workgroups are handed out per CU, so the launch takes as long as the CU
+  // with the most tiles -- 300 tiles on 256 CUs cost two tile times for 1.17 tiles' worth of work
+  // each.  64-wide tiles quantise four times finer; their kernel peaks ~6 % lower (twice the LDS
+  // reads per FLOP).  Take whichever the fill predicts to be faster (measured on the ViT-B shapes
+  // at batch 8..64: within a few percent of the better choice everywhere, up to +50 %).
+  if (pl->tile == 128 && s == 1 && a->reserved != 1) {
+    const long long slots = 256 * kBlocksPerCU;
+    const long long t128 = (long long)pl->tiles_m * pl->tiles_n * pl->batch;
+    const long long t64 = (long long)((a->M + 63) / 64) * ((a->N + 63) / 64) * pl->batch;
+    auto fill = [](long long n) { return (double)n / (256.0 * (double)((n + 255) / 256)); };
+    // a small remainder after whole rounds is cut off and run on 64-wide tiles anyway (tail round)
+    double e128 = (t128 >= slots && t128 % slots <= 128) ? 0.98 : fill(t128);
+    if (t128 < 512) e128 *= 0.9;  // fewer than two workgroups per CU: latencies show
+    const double e64 = fill(t64) * 0.94;
+    if (e64 > e128) {
+      pl->tile = 64;
+      pl->tiles_m = (a->M + 63) / 64;
+      pl->tiles_n = (a->N + 63) / 64;
+    }
+  }
   return 0;
 }
 
