@@ -605,7 +605,9 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
   const bool plain0 = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
   const long long t128 = (long long)((a->M + 127) / 128) * ((a->N + 127) / 128) * pl->batch;
   const bool can_split = plain0 && a->split_k != 1 && a->K >= 4096;
-  pl->tile = (a->reserved != 1 && a->M >= 128 && a->N >= 128 && (t128 >= 64 || can_split)) ? 128 : 64;
+  // N a multiple of 64 but not of 128 (D = 192, 3D = 576): 64-wide tiles keep the unguarded path
+  const bool n_wants_64 = a->N % 128 != 0 && a->N % 64 == 0;
+  pl->tile = (a->reserved != 1 && !n_wants_64 && a->M >= 128 && a->N >= 128 && (t128 >= 64 || can_split)) ? 128 : 64;
   pl->tiles_m = (a->M + pl->tile - 1) / pl->tile;
   pl->tiles_n = (a->N + pl->tile - 1) / pl->tile;
   const bool plain = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
