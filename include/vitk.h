@@ -137,6 +137,15 @@ int vitk_gelu_bwd(const float *x, const float *dy, int64_t n, float *dx, vitk_st
 int vitk_dropout_fwd(const float *x, int64_t n, float rate, uint64_t seed, uint64_t offset, float *y, float *mask,
                      vitk_stream_t stream);
 int vitk_dropout_bwd(const float *dy, const float *mask, int64_t n, float *dx, vitk_stream_t stream);
+/* The same forward with the skip connection folded in, y = residual + x*mask (residual may be
+ * NULL), and with the mask optional: the factors are a pure function of (seed, offset, element
+ * index), so the backward can regenerate them instead of reading a stored mask:
+ * vitk_dropout_stream_bwd gives dx = dy*mask for the mask of the forward call with the same
+ * (rate, seed, offset).  (x + dropout(...) in src/model/TransformerEncoderBlock.cpp:28,34.) */
+int vitk_dropout_residual_fwd(const float *x, const float *residual, int64_t n, float rate, uint64_t seed,
+                              uint64_t offset, float *y, float *mask, vitk_stream_t stream);
+int vitk_dropout_stream_bwd(const float *dy, int64_t n, float rate, uint64_t seed, uint64_t offset, float *dx,
+                            vitk_stream_t stream);
 
 /* ---- element-wise helpers (Tensor::operator+, src/core/Tensor.cpp:316-351; fill :128-137) ----- */
 int vitk_add_f32(const float *a, const float *b, int64_t n, float *out, vitk_stream_t stream);

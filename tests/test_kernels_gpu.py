@@ -246,6 +246,16 @@ def test_dropout(K):
     Y3, M3 = empty(1001), empty(1001)
     K.call("vitk_dropout_fwd", dev(x)[1:], 1001, rate, 1234, 0, Y3, M3, K.stream())
     np.testing.assert_array_equal(host(M3), m[:1001])
+    # skip connection folded in, mask not stored; backward regenerates the factors from the stream
+    res = V.rng_normal(3, n)
+    K.call("vitk_dropout_residual_fwd", dev(x), dev(res), n, rate, 1234, 0, Y2, None, K.stream())
+    np.testing.assert_array_equal(host(Y2), res + x * m)
+    K.call("vitk_dropout_residual_fwd", dev(x), None, n, rate, 1234, 0, Y2, None, K.stream())
+    np.testing.assert_array_equal(host(Y2), y)
+    K.call("vitk_dropout_stream_bwd", dev(dy), n, rate, 1234, 0, DX, K.stream())
+    np.testing.assert_array_equal(host(DX), dy * m)
+    K.call("vitk_dropout_stream_bwd", dev(dy)[1:], 1001, rate, 1234, 0, Y3, K.stream())  # scalar path
+    np.testing.assert_array_equal(host(Y3), dy[1:1002] * m[:1001])
 
 
 def test_add_scale_fill_copy(K):

@@ -135,29 +135,61 @@ __device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * (1.0
 
 // One Philox block per group of 4 consecutive elements: element i uses word i%4 of block
 // offset + i/4, so the mask does not depend on the launch geometry.
-__global__ void dropout_fwd_kernel(const float *__restrict__ x, long long n, float rate, float scale,
-                                   unsigned long long seed, unsigned long long offset, float *__restrict__ y,
-                                   float *__restrict__ mask, bool vec) {
+__device__ __forceinline__ void dropout_factors(unsigned long long block, unsigned long long seed, float rate,
+                                                float scale, float (&m)[4]) {
+  const uint4 r = philox4x32(block, seed);
+  m[0] = u01(r.x) < rate ? 0.f : scale;
+  m[1] = u01(r.y) < rate ? 0.f : scale;
+  m[2] = u01(r.z) < rate ? 0.f : scale;
+  m[3] = u01(r.w) < rate ? 0.f : scale;
+}
+
+// y = x * m (+ residual); mask (optional) receives m.
+__global__ void dropout_fwd_kernel(const float *__restrict__ x, const float *__restrict__ residual, long long n,
+                                   float rate, float scale, unsigned long long seed, unsigned long long offset,
+                                   float *__restrict__ y, float *__restrict__ mask, bool vec) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const long long n4 = (n + 3) >> 2;
   for (long long i = tid; i < n4; i += stride) {
-    const uint4 r = philox4x32(offset + (unsigned long long)i, seed);
     float m[4];
-    m[0] = u01(r.x) < rate ? 0.f : scale;
-    m[1] = u01(r.y) < rate ? 0.f : scale;
-    m[2] = u01(r.z) < rate ? 0.f : scale;
-    m[3] = u01(r.w) < rate ? 0.f : scale;
+    dropout_factors(offset + (unsigned long long)i, seed, rate, scale, m);
     const long long e = i << 2;
     if (vec && e + 3 < n) {
       const float4 v = reinterpret_cast<const float4 *>(x)[i];
-      reinterpret_cast<float4 *>(mask)[i] = make_float4(m[0], m[1], m[2], m[3]);
-      reinterpret_cast<float4 *>(y)[i] = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+      float4 o = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+      if (residual != nullptr) {
+        const float4 r = reinterpret_cast<const float4 *>(residual)[i];
+        o = make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w);
+      }
+      if (mask != nullptr) reinterpret_cast<float4 *>(mask)[i] = make_float4(m[0], m[1], m[2], m[3]);
+      reinterpret_cast<float4 *>(y)[i] = o;
     } else {
       for (int j = 0; j < 4 && e + j < n; ++j) {
-        mask[e + j] = m[j];
-        y[e + j] = x[e + j] * m[j];
+        if (mask != nullptr) mask[e + j] = m[j];
+        const float o = x[e + j] * m[j];
+        y[e + j] = residual != nullptr ? residual[e + j] + o : o;
       }
+    }
+  }
+}
+
+// dx = dy * m with m regenerated from the stream position of the forward call.
+__global__ void dropout_bwd_stream_kernel(const float *__restrict__ dy, long long n, float rate, float scale,
+                                          unsigned long long seed, unsigned long long offset, float *__restrict__ dx,
+                                          bool vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long n4 = (n + 3) >> 2;
+  for (long long i = tid; i < n4; i += stride) {
+    float m[4];
+    dropout_factors(offset + (unsigned long long)i, seed, rate, scale, m);
+    const long long e = i << 2;
+    if (vec && e + 3 < n) {
+      const float4 g = reinterpret_cast<const float4 *>(dy)[i];
+      reinterpret_cast<float4 *>(dx)[i] = make_float4(g.x * m[0], g.y * m[1], g.z * m[2], g.w * m[3]);
+    } else {
+      for (int j = 0; j < 4 && e + j < n; ++j) dx[e + j] = dy[e + j] * m[j];
     }
   }
 }
@@ -192,14 +224,34 @@ int vitk_gelu_bwd(const float *x, const float *dy, int64_t n, float *dx, vitk_st
 
 int vitk_dropout_fwd(const float *x, int64_t n, float rate, uint64_t seed, uint64_t offset, float *y, float *mask,
                      vitk_stream_t stream) {
-  VITK_REQUIRE(n >= 0 && (n == 0 || (x && y && mask)), "vitk_dropout_fwd: bad arguments");
+  VITK_REQUIRE(mask != nullptr || n == 0, "vitk_dropout_fwd: null mask");
+  return vitk_dropout_residual_fwd(x, nullptr, n, rate, seed, offset, y, mask, stream);
+}
+
+int vitk_dropout_residual_fwd(const float *x, const float *residual, int64_t n, float rate, uint64_t seed,
+                              uint64_t offset, float *y, float *mask, vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (x && y)), "vitk_dropout_fwd: bad arguments");
   VITK_REQUIRE(rate >= 0.0f && rate < 1.0f, "vitk_dropout_fwd: rate %g outside [0,1)", (double)rate);
   if (n == 0) return 0;
   const float scale = rate > 0.0f ? 1.0f / (1.0f - rate) : 1.0f;
-  const bool vec = vitk::aligned16(x) && vitk::aligned16(y) && vitk::aligned16(mask);
+  const bool vec = vitk::aligned16(x) && vitk::aligned16(y) && vitk::aligned16(mask) && vitk::aligned16(residual);
   hipLaunchKernelGGL(dropout_fwd_kernel, dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0, vitk::as_stream(stream), x,
-                     (long long)n, rate, scale, (unsigned long long)seed, (unsigned long long)offset, y, mask, vec);
+                     residual, (long long)n, rate, scale, (unsigned long long)seed, (unsigned long long)offset, y, mask,
+                     vec);
   return vitk::check_launch("vitk_dropout_fwd");
+}
+
+int vitk_dropout_stream_bwd(const float *dy, int64_t n, float rate, uint64_t seed, uint64_t offset, float *dx,
+                            vitk_stream_t stream) {
+  VITK_REQUIRE(n >= 0 && (n == 0 || (dy && dx)), "vitk_dropout_stream_bwd: bad arguments");
+  VITK_REQUIRE(rate >= 0.0f && rate < 1.0f, "vitk_dropout_stream_bwd: rate %g outside [0,1)", (double)rate);
+  if (n == 0) return 0;
+  const float scale = rate > 0.0f ? 1.0f / (1.0f - rate) : 1.0f;
+  const bool vec = vitk::aligned16(dy) && vitk::aligned16(dx);
+  hipLaunchKernelGGL(dropout_bwd_stream_kernel, dim3(vitk::grid_for(n / 4 + 1, TPB)), dim3(TPB), 0,
+                     vitk::as_stream(stream), dy, (long long)n, rate, scale, (unsigned long long)seed,
+                     (unsigned long long)offset, dx, vec);
+  return vitk::check_launch("vitk_dropout_stream_bwd");
 }
 
 int vitk_dropout_bwd(const float *dy, const float *mask, int64_t n, float *dx, vitk_stream_t stream) {

@@ -1,7 +1,11 @@
 // Inverted dropout (reference: include/layers/Dropout.hpp, src/layers/Dropout.cpp): identity when
 // not training or rate == 0; otherwise mask in {0, 1/(1-rate)} drawn on the device (Philox).
+// The mask is a pure function of the stream position of the forward call, so it is never stored:
+// backward regenerates it.
 #ifndef DROPOUT_HPP
 #define DROPOUT_HPP
+
+#include <cstdint>
 
 #include "layers/Layer.hpp"
 
@@ -10,13 +14,17 @@ public:
   explicit Dropout(float rate = 0.5f);
   Tensor forward(const Tensor &input, bool isTraining) override;
   Tensor backward(const Tensor &outputGradient) override;
+  // residual + dropout(input) in one pass (the skip connections of the encoder block)
+  Tensor forwardAdd(const Tensor &input, const Tensor &residual, bool isTraining);
   std::string getName() const override { return "Dropout"; }
   bool active(bool isTraining) const { return isTraining && rate != 0.0f; }
 
 private:
   float rate;
   float scale;
-  Tensor mask;
+  // stream position and extent of the last training-mode forward (count 0: none)
+  uint64_t seed = 0, offset = 0;
+  size_t count = 0;
 };
 
 #endif  // DROPOUT_HPP

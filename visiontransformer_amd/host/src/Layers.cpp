@@ -192,26 +192,44 @@ Dropout::Dropout(float rate) : rate(rate) {
 }
 
 Tensor Dropout::forward(const Tensor &input, bool isTraining) {
-  if (!isTraining || rate == 0.0f) return input;
+  if (!isTraining || rate == 0.0f) {
+    count = 0;
+    return input;
+  }
   if (!input.isContiguous()) throw std::runtime_error("Dropout::forward actualmente solo soporta tensores contiguos.");
-  mask = Tensor::deviceEmpty(input.getShape());
   Tensor y = Tensor::deviceEmpty(input.getShape());
-  uint64_t seed, offset;
-  vit::dropout_stream(input.getSize(), &seed, &offset);
-  vit::check(vitk_dropout_fwd(input.deviceData(), (int64_t)input.getSize(), rate, seed, offset, y.deviceDataOverwrite(),
-                              mask.deviceDataOverwrite(), S()),
-             "vitk_dropout_fwd");
+  count = input.getSize();
+  vit::dropout_stream(count, &seed, &offset);
+  vit::check(vitk_dropout_residual_fwd(input.deviceData(), nullptr, (int64_t)count, rate, seed, offset,
+                                       y.deviceDataOverwrite(), nullptr, S()),
+             "vitk_dropout_residual_fwd");
+  return y;
+}
+
+Tensor Dropout::forwardAdd(const Tensor &input, const Tensor &residual, bool isTraining) {
+  if (!isTraining || rate == 0.0f) {
+    count = 0;
+    return residual + input;
+  }
+  if (!input.isContiguous() || !residual.isContiguous() || input.getSize() != residual.getSize())
+    throw std::runtime_error("Dropout::forwardAdd espera dos tensores contiguos del mismo tamano.");
+  Tensor y = Tensor::deviceEmpty(input.getShape());
+  count = input.getSize();
+  vit::dropout_stream(count, &seed, &offset);
+  vit::check(vitk_dropout_residual_fwd(input.deviceData(), residual.deviceData(), (int64_t)count, rate, seed, offset,
+                                       y.deviceDataOverwrite(), nullptr, S()),
+             "vitk_dropout_residual_fwd");
   return y;
 }
 
 Tensor Dropout::backward(const Tensor &outputGradient) {
-  if (mask.getSize() == 0) return outputGradient;  // forward ran in inference mode or with rate 0
-  if (!outputGradient.isContiguous())
-    throw std::runtime_error("Dropout::backward actualmente solo soporta tensores contiguos.");
+  if (count == 0) return outputGradient;  // forward ran in inference mode or with rate 0
+  if (!outputGradient.isContiguous() || outputGradient.getSize() != count)
+    throw std::runtime_error("Dropout::backward espera un gradiente contiguo con la forma de la entrada.");
   Tensor dx = Tensor::deviceEmpty(outputGradient.getShape());
-  vit::check(vitk_dropout_bwd(outputGradient.deviceData(), mask.deviceData(), (int64_t)outputGradient.getSize(),
-                              dx.deviceDataOverwrite(), S()),
-             "vitk_dropout_bwd");
+  vit::check(vitk_dropout_stream_bwd(outputGradient.deviceData(), (int64_t)count, rate, seed, offset,
+                                     dx.deviceDataOverwrite(), S()),
+             "vitk_dropout_stream_bwd");
   return dx;
 }
 
@@ -231,10 +249,7 @@ Tensor FeedForward::forwardFused(const Tensor &input, bool isTraining, const Ten
   Tensor h = dense1.forwardFused(input, isTraining, VITK_ACT_GELU_FWD, isTraining ? &preActivation : nullptr, nullptr);
   const bool drop = dropout.active(isTraining);
   Tensor y = dense2.forwardFused(h, isTraining, VITK_ACT_NONE, nullptr, drop ? nullptr : residual);
-  if (drop) {
-    y = dropout.forward(y, isTraining);
-    if (residual) y = *residual + y;
-  }
+  if (drop) y = residual ? dropout.forwardAdd(y, *residual, isTraining) : dropout.forward(y, isTraining);
   return y;
 }
 

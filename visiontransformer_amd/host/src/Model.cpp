@@ -25,8 +25,7 @@ Tensor TransformerEncoderBlock::forward(const Tensor &input, bool isTraining) {
   Tensor residual1;
   if (attention_dropout.active(isTraining)) {
     x = attention.forward(x, isTraining);
-    x = attention_dropout.forward(x, isTraining);
-    residual1 = input + x;
+    residual1 = attention_dropout.forwardAdd(x, input, isTraining);
   } else {
     residual1 = attention.forwardFused(x, isTraining, &input);  // add fused into out_proj's epilogue
   }

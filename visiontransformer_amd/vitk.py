@@ -56,6 +56,8 @@ SIGNATURES = {
     "vitk_gelu_bwd": (C.c_int, [_p, _p, _i64, _p, _p]),
     "vitk_dropout_fwd": (C.c_int, [_p, _i64, _f, _u64, _u64, _p, _p, _p]),
     "vitk_dropout_bwd": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "vitk_dropout_residual_fwd": (C.c_int, [_p, _p, _i64, _f, C.c_uint64, C.c_uint64, _p, _p, _p]),
+    "vitk_dropout_stream_bwd": (C.c_int, [_p, _i64, _f, C.c_uint64, C.c_uint64, _p, _p]),
     "vitk_add_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "vitk_add3_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p]),
     "vitk_scale_f32": (C.c_int, [_p, _f, _i64, _p, _p]),
