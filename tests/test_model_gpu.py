@@ -317,9 +317,11 @@ def test_im2col_mode_reads_true_patches_and_exact_dk_matches_autograd(H):
         off += k
 
 
-@pytest.mark.parametrize("name,B", [("C1", 128), ("C2", 64)])
+@pytest.mark.parametrize("name,B", [("C1", 128), ("C2", 64), ("C3", 3), ("C4", 1), ("C5", 2)])
 def test_model_vs_oracle_at_baseline_shapes(H, name, B):
-    """BASELINE config 0 at its full batch (and config 1's shape) against the CPU oracle."""
+    """The reference's own configurations at their full batch, and the 224x224 ViT-Ti / ViT-S
+    shapes (ViT-B included) at the batch the CPU oracle finishes in seconds (197-token sequences, ragged row
+    counts, D = 192 and 384), against the CPU oracle."""
     O = V.oracle()
     cfgd = V.CONFIGS[name]
     ocfg = V.Cfg.make(**cfgd)
