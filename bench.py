@@ -96,6 +96,11 @@ def measured_traffic(kernel):
 
 
 def main():
+    # stdout carries exactly one line, the result: everything libraries print on the way (RCCL's
+    # version banner, for one) goes to stderr, and the JSON line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -213,7 +218,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgd)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
