@@ -114,8 +114,8 @@ struct KContig {
     }
   }
   // FULL path: per-lane byte offsets inside the tile (constant over the K loop); the tile origin
-  // is a uniform pointer that advances by slab_bytes() per slab, so the loop needs no vector
-  // address arithmetic.
+  // is the base of a buffer descriptor and a scalar offset advances by slab_bytes() per slab, so
+  // the loop needs no vector address arithmetic.
   __device__ static void lane_offsets(long long ld, unsigned (&off)[NL]) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
@@ -814,7 +814,7 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
 }
 
 #ifdef VITK_GEMM_STAMPS
-// Diagnostic build only: device buffer of 8 x uint64 per workgroup of the next launches (or null).
+// Diagnostic build only: device buffer of 16 x uint64 per workgroup of the next launches (or null).
 extern "C" void vitk_gemm_set_stamps(unsigned long long *device_buffer) { g_stamps = device_buffer; }
 #endif
 
