@@ -48,7 +48,19 @@ struct SdpaParams {
   float scale;
   int dk_mode;
   int vec;                 // all pointers 16-byte aligned, all pitches and dh multiples of 4
+#ifdef VITK_SDPA_STAMPS
+  unsigned long long *dbg;  // diagnostic build only: 16 clock stamps per wave
+#endif
 };
+// Diagnostic build (-DVITK_SDPA_STAMPS, tools/sdpa_stamps.py): lane 0 of every wave of the fused
+// backward records the shader clock at the phase boundaries of query-tile iteration 3.
+#ifdef VITK_SDPA_STAMPS
+unsigned long long *g_sdpa_dbg = nullptr;
+#define SD_STAMP(k) if (p.dbg && lane == 0 && i == 3) p.dbg[((long long)blockIdx.x * 8 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define SD_STAMP(k)
+#endif
+
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
@@ -469,6 +481,7 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaPara
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(qt[jj * PT], kf[jj], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[jj * PT], vf[jj], dp, 0, 0, 0);
       }
+      SD_STAMP(1)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ss + 8 * g);
@@ -482,6 +495,7 @@ __global__ __launch_bounds__(THREADS, 2) void sdpa_bwd_dkv_kernel(const SdpaPara
           dp[r] = (pr * (dp[r] - d4[e])) * p.scale;
         }
       }
+      SD_STAMP(2)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -587,6 +601,7 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
   VITK_STORE_TILE()
   __syncthreads();
   for (int i = 0; i < nt; ++i) {
+    SD_STAMP(0)
     if (i + 1 < nt) VITK_LOAD_TILE(i + 1)
     if (active) {
       const float *qt = tile + (HALF * lh) * PT + li, *gt = qt + TRANS;
@@ -598,6 +613,7 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(qt[jj * PT], kf[jj], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[jj * PT], vf[jj], dp, 0, 0, 0);
       }
+      SD_STAMP(1)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ss + 8 * g);
@@ -612,6 +628,7 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
           tb[li * PT + VITK_ROW_OF(r) + 4 * lh] = dp[r];  // dS[query][key] -> tb[key][query]
         }
       }
+      SD_STAMP(2)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -619,6 +636,7 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
           dv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[VITK_ROW_OF(r) * PW + 32 * t], s[r], dv[t], 0, 0, 0);
           dk[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[VITK_ROW_OF(r) * PW + 32 * t], dp[r], dk[t], 0, 0, 0);
         }
+      SD_STAMP(3)
       // this wave's share of dQ^T[d][query] = sum over its keys of K[key][d] dS^T[key][query]
       f32x16 dq[DT];
 #pragma unroll
@@ -629,6 +647,7 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
 #pragma unroll
         for (int t = 0; t < DT; ++t) dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kpl[2 * r + t], dst, dq[t], 0, 0, 0);
       }
+      SD_STAMP(4)
       float *rb = rb_all + wave * F_RB + li * F_RBP + 4 * lh;
 #pragma unroll
       for (int t = 0; t < DT; ++t)
@@ -638,7 +657,9 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
           *reinterpret_cast<f32x4 *>(rb + 32 * t + 8 * g) = v;
         }
     }
+    SD_STAMP(5)
     __syncthreads();  // every wave is done with this query tile; all partial dQ tiles are in LDS
+    SD_STAMP(6)
     if (i + 1 < nt) VITK_STORE_TILE()
     {
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
@@ -647,7 +668,9 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
       if (row < p.N && col_ok)
         *reinterpret_cast<f32x4 *>(p.dq + ((long long)b * p.N + row) * p.ldg + (long long)h * p.dh + c0) = sum;
     }
+    SD_STAMP(7)
     __syncthreads();  // next query tile staged; partial buffers free again
+    SD_STAMP(8)
   }
 #undef VITK_LOAD_TILE
 #undef VITK_STORE_TILE
@@ -756,6 +779,9 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   p.stats = const_cast<float *>(stats); p.dsum = workspace;
   p.dq = dq; p.dk = dk; p.dv = dv; p.ldg = ld_dqkv;
   p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale; p.dk_mode = dk_mode;
+#ifdef VITK_SDPA_STAMPS
+  p.dbg = g_sdpa_dbg;
+#endif
   p.vec = all_vec({q, k, v, out, dout, dq, dk, dv}, {ld_qkv, ld_out, ld_dqkv, dh});
   hipStream_t st = vitk::as_stream(stream);
   const dim3 grid((unsigned)blocks);
@@ -765,4 +791,7 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   return launch_bwd_fused(p, st);  // 32 < dh <= 64: one workgroup per head
 }
 
+#ifdef VITK_SDPA_STAMPS
+void vitk_sdpa_set_stamps(unsigned long long *b) { g_sdpa_dbg = b; }
+#endif
 }  // extern "C"
