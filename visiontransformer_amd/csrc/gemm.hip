@@ -21,6 +21,7 @@
 // sub-tile edge): the loop is MFMA-paced.
 #include "common.h"
 
+#include <cstdio>
 #include <type_traits>
 #include <vector>
 
@@ -141,6 +142,27 @@ struct KContig {
       d[3 * LD] = reg[it].w;
     }
   }
+  // The same store into the ring slot at literal byte offset OFF: one loop-invariant address
+  // register per staged vector (lds_bases) and four ds_write_b32 whose slot and k-row offsets
+  // are instruction immediates.  (Left to the compiler these become paired writes with 8-bit
+  // offsets, which need a separate address register per slot and k-row pair.)
+  __device__ static void lds_bases(const float *s, unsigned (&base)[NL]) {
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int q = threadIdx.x + THREADS * it;
+      base[it] = (unsigned)(uintptr_t)(s + ((q % (BK / 4)) * 4) * LD + q / (BK / 4));
+    }
+  }
+  template <int OFF>
+  __device__ static void store_imm(const unsigned (&base)[NL], const f32x4 (&reg)[NL]) {
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(base[it]), "v"(reg[it].x), "n"(OFF) : "memory");
+      asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(base[it]), "v"(reg[it].y), "n"(OFF + LD * 4) : "memory");
+      asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(base[it]), "v"(reg[it].z), "n"(OFF + 2 * LD * 4) : "memory");
+      asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(base[it]), "v"(reg[it].w), "n"(OFF + 3 * LD * 4) : "memory");
+    }
+  }
 };
 
 // Operand whose m/n index is contiguous in memory: element (k, row) at base[k*ld + row].
@@ -191,6 +213,20 @@ struct MnContig {
       *reinterpret_cast<f32x4 *>(s + kk * LD + rq * 4) = reg[it];
     }
   }
+  // literal ring-slot offset: the compiler folds it into the 16-byte store's immediate by itself
+  __device__ static void lds_bases(const float *s, unsigned (&base)[NL]) {
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int q = threadIdx.x + THREADS * it;
+      base[it] = (unsigned)(uintptr_t)(s + (q / (ROWS / 4)) * LD + (q % (ROWS / 4)) * 4);
+    }
+  }
+  template <int OFF>
+  __device__ static void store_imm(const unsigned (&base)[NL], const f32x4 (&reg)[NL]) {
+#pragma unroll
+    for (int it = 0; it < NL; ++it)
+      *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>((uintptr_t)(base[it] + OFF)) = reg[it];
+  }
 };
 
 template <bool KC, int ROWS>
@@ -207,8 +243,10 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 // FULL: all operands allow 16-byte accesses and N is made of whole tiles; the loop carries no
 // bounds checks at all (a ragged last tile row, and a ragged contraction of a weight-gradient
 // product, are cut off by the extents of the buffer descriptors), the epilogue only a row mask.
-template <int TILE, bool TA, bool TB, bool FULL>
+// CS: also form the column sums of B (only with an untransposed B).
+template <int TILE, bool TA, bool TB, bool FULL, bool CS>
 __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Params p) {
+  static_assert(!(CS && TB), "column sums need an untransposed B");
   using OpA = Operand<!TA, TILE>;  // A is k-contiguous when not transposed
   using OpB = Operand<TB, TILE>;   // B is k-contiguous when transposed
   constexpr int WT = TILE / 2;     // per-wave tile
@@ -326,12 +364,12 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   // On the FULL path the second operand goes into the MFMA as the row operand: the accumulator
   // tile is C^T, i.e. each lane ends up with runs of 4 consecutive columns of one row of C
   // (16-byte stores); the guarded path keeps plain accumulators (row-segment stores, any edge).
-#define VITK_SLAB(T, RA, RB, STEADY)                                                                                \
+#define VITK_SLAB(T, RA, RB, STEADY, CUR, STG)                                                                 \
   {                                                                                                         \
-    const int nxt = cur == STAGES - 1 ? 0 : cur + 1;                                                        \
+    const int nxt = (CUR) == STAGES - 1 ? 0 : (CUR) + 1;                                                    \
     const int fre = nxt == STAGES - 1 ? 0 : nxt + 1;                                                        \
-    const float *__restrict__ as = As + cur * SA + lane_a;                                                  \
-    const float *__restrict__ bs = Bs + cur * SB + lane_b;                                                  \
+    const float *__restrict__ as = As + (CUR)*SA + lane_a;                                                  \
+    const float *__restrict__ bs = Bs + (CUR)*SB + lane_b;                                                  \
     const float *__restrict__ as_n = As + nxt * SA + lane_a;                                                \
     const float *__restrict__ bs_n = Bs + nxt * SB + lane_b;                                                \
     _Pragma("unroll") for (int ks = 0; ks < STEPS; ++ks) {                                                  \
@@ -352,7 +390,7 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       if (ks == STEPS / 2 - 1) {                                                                               \
         lds_barrier();                                                                                      \
         if (STEADY || (T) + 2 < nslab) {                                                                    \
-          VITK_STAGE(fre, RA, RB)                                                                           \
+          STG(fre, RA, RB)                                                                                  \
         }                                                                                                   \
         if (STEADY || (T) + 4 < nslab) {                                                                    \
           VITK_FETCH((T) + 4, RA, RB)                                                                       \
@@ -360,18 +398,28 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
         __builtin_amdgcn_sched_barrier(0); /* keep the loads here: sunk below the MFMAs they lose cover */ \
       }                                                                                                     \
     }                                                                                                       \
-    cur = nxt;                                                                                              \
   }
+#define VITK_ADVANCE() cur = cur == STAGES - 1 ? 0 : cur + 1;
 
   // Column sums of B ride along: the workgroups of the first tile row add up what they stage.
-  const bool do_colsum = !TB && p.colsum != nullptr && tm == 0;
+  const bool do_colsum = CS && tm == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  unsigned lbase_a[OpA::NL], lbase_b[OpB::NL];
+  OpA::lds_bases(As, lbase_a);
+  OpB::lds_bases(Bs, lbase_b);
+#define VITK_STAGE_SUMS(RB)                                                               \
+  if constexpr (CS) {                                                                     \
+    /* every workgroup adds (a branch on do_colsum costs more registers than the adds cost time) */ \
+    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) csum += RB[it];                \
+  }
+#define VITK_STAGE_LIT(SLOT, RA, RB)                                                      \
+  OpA::template store_imm<(SLOT)*SA * 4>(lbase_a, RA);                                    \
+  OpB::template store_imm<(SLOT)*SB * 4>(lbase_b, RB);                                    \
+  VITK_STAGE_SUMS(RB)
 #define VITK_STAGE(SLOT, RA, RB)                                                          \
   OpA::store(As + (SLOT)*SA, RA);                                                         \
   OpB::store(Bs + (SLOT)*SB, RB);                                                         \
-  if constexpr (!TB) {                                                                    \
-    _Pragma("unroll") for (int it = 0; it < OpB::NL; ++it) csum += RB[it]; /* used only if do_colsum */ \
-  }
+  VITK_STAGE_SUMS(RB)
 
   // Long contractions: a straight-line prologue and a condition-free steady state in ONE branch,
   // so the compiler counts the loads in flight exactly and a slab waits only for the older of
@@ -385,9 +433,22 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     VITK_FETCH(2, ra0, rb0)
     VITK_FETCH(3, ra1, rb1)
     VITK_FIRST_OPERANDS()
-    for (; t + 5 < nslab; t += 2) {
-      VITK_SLAB(t, ra0, rb0, true)
-      VITK_SLAB(t + 1, ra1, rb1, true)
+    // six slabs per trip = both register sets x all three ring slots: every LDS address in here is
+    // a loop-invariant register plus a literal, so the trip carries no address arithmetic (vector
+    // instructions do not overlap with fp32 MFMAs, they take their place)
+    for (; t + 9 < nslab; t += 6) {
+      VITK_SLAB(t, ra0, rb0, true, 0, VITK_STAGE_LIT)
+      VITK_SLAB(t + 1, ra1, rb1, true, 1, VITK_STAGE_LIT)
+      VITK_SLAB(t + 2, ra0, rb0, true, 2, VITK_STAGE_LIT)
+      VITK_SLAB(t + 3, ra1, rb1, true, 0, VITK_STAGE_LIT)
+      VITK_SLAB(t + 4, ra0, rb0, true, 1, VITK_STAGE_LIT)
+      VITK_SLAB(t + 5, ra1, rb1, true, 2, VITK_STAGE_LIT)
+    }
+    for (; t + 5 < nslab; t += 2) {  // (ring slot 0 again on entry)
+      VITK_SLAB(t, ra0, rb0, true, cur, VITK_STAGE)
+      VITK_ADVANCE()
+      VITK_SLAB(t + 1, ra1, rb1, true, cur, VITK_STAGE)
+      VITK_ADVANCE()
     }
   } else {
     if (nslab > 0) {
@@ -407,16 +468,23 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     VITK_FIRST_OPERANDS()
   }
   for (; t < nslab; t += 2) {
-    VITK_SLAB(t, ra0, rb0, false)
-    if (t + 1 < nslab) VITK_SLAB(t + 1, ra1, rb1, false)
+    VITK_SLAB(t, ra0, rb0, false, cur, VITK_STAGE)
+    VITK_ADVANCE()
+    if (t + 1 < nslab) {
+      VITK_SLAB(t + 1, ra1, rb1, false, cur, VITK_STAGE)
+      VITK_ADVANCE()
+    }
   }
+#undef VITK_ADVANCE
 #undef VITK_SLAB
 #undef VITK_STAGE
+#undef VITK_STAGE_LIT
+#undef VITK_STAGE_SUMS
 #undef VITK_FIRST_OPERANDS
 #undef VITK_FETCH
   VITK_STAMP(2)
 
-  if constexpr (!TB) {
+  if constexpr (CS) {
     if (do_colsum) {  // workgroup-uniform
       // Thread t summed rows t / (TILE/4) (+ multiples) of columns 4*(t % (TILE/4)) .. +3: add the
       // THREADS / (TILE/4) row groups in a fixed order through LDS (the ring is free by now).
@@ -645,10 +713,13 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
 
 template <int TILE, bool FULL>
 void launch2(const Params &p, bool ta, bool tb, dim3 grid, hipStream_t st) {
-  if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, false, FULL>), grid, dim3(THREADS), 0, st, p);
-  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, true, FULL>), grid, dim3(THREADS), 0, st, p);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, true, false, FULL>), grid, dim3(THREADS), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<TILE, true, true, FULL>), grid, dim3(THREADS), 0, st, p);
+  const bool cs = p.colsum != nullptr;
+  if (!ta && !tb && !cs) hipLaunchKernelGGL((gemm_kernel<TILE, false, false, FULL, false>), grid, dim3(THREADS), 0, st, p);
+  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, false, FULL, true>), grid, dim3(THREADS), 0, st, p);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, true, FULL, false>), grid, dim3(THREADS), 0, st, p);
+  else if (ta && !tb && !cs) hipLaunchKernelGGL((gemm_kernel<TILE, true, false, FULL, false>), grid, dim3(THREADS), 0, st, p);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, true, false, FULL, true>), grid, dim3(THREADS), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<TILE, true, true, FULL, false>), grid, dim3(THREADS), 0, st, p);
 }
 
 template <int TILE>
@@ -684,8 +755,8 @@ hipEvent_t prof_event() {
   return e;
 }
 
-int variant_of(int tile, bool ta, bool tb, bool full) {
-  return (full ? 8 : 0) + (tile == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0);
+int variant_of(int tile, bool ta, bool tb, bool full, bool cs) {
+  return (cs ? 16 : 0) + (full ? 8 : 0) + (tile == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0);
 }
 
 }  // namespace
@@ -791,7 +862,7 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
                     (pl.split_k == 1 || vitk::aligned16(a->workspace));
   ProfRec rec{};
   if (g_prof_on) {
-    rec.variant = variant_of(pl.tile, a->trans_a != 0, a->trans_b != 0, full);
+    rec.variant = variant_of(pl.tile, a->trans_a != 0, a->trans_b != 0, full, a->colsum_b != nullptr);
     rec.flops = 2.0 * a->M * a->N * a->K * pl.batch;
     rec.e0 = prof_event();
     rec.e1 = prof_event();
@@ -825,7 +896,7 @@ extern "C" int vitk_gemm_profile_enable(int on) {
 
 extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *total_flops, int64_t *launches,
                                       int reset) {
-  VITK_REQUIRE(variant >= 0 && variant < 16, "vitk_gemm_profile_read: variant %d outside [0,16)", variant);
+  VITK_REQUIRE(variant >= 0 && variant < 32, "vitk_gemm_profile_read: variant %d outside [0,32)", variant);
   double ms = 0.0, fl = 0.0;
   int64_t n = 0;
   for (const ProfRec &r : g_prof) {
@@ -853,14 +924,11 @@ extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *tot
 }
 
 extern "C" const char *vitk_gemm_variant_name(int variant) {
-  static const char *names[16] = {
-      "gemm_kernel<128, false, false, false>", "gemm_kernel<128, false, true, false>",
-      "gemm_kernel<128, true, false, false>",  "gemm_kernel<128, true, true, false>",
-      "gemm_kernel<64, false, false, false>",  "gemm_kernel<64, false, true, false>",
-      "gemm_kernel<64, true, false, false>",   "gemm_kernel<64, true, true, false>",
-      "gemm_kernel<128, false, false, true>",  "gemm_kernel<128, false, true, true>",
-      "gemm_kernel<128, true, false, true>",   "gemm_kernel<128, true, true, true>",
-      "gemm_kernel<64, false, false, true>",   "gemm_kernel<64, false, true, true>",
-      "gemm_kernel<64, true, false, true>",    "gemm_kernel<64, true, true, true>"};
-  return (variant >= 0 && variant < 16) ? names[variant] : "";
+  // the names a profiler prints: gemm_kernel<TILE, TA, TB, FULL, CS>
+  static char names[32][48];
+  if (variant < 0 || variant >= 32) return "";
+  const bool cs = variant & 16, full = variant & 8, t64 = variant & 4, ta = variant & 2, tb = variant & 1;
+  std::snprintf(names[variant], sizeof names[variant], "gemm_kernel<%d, %s, %s, %s, %s>", t64 ? 64 : 128,
+                ta ? "true" : "false", tb ? "true" : "false", full ? "true" : "false", cs ? "true" : "false");
+  return names[variant];
 }

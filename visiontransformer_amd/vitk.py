@@ -172,7 +172,7 @@ def gemm_profile(enable):
 def gemm_profile_read(reset=True):
     """Per kernel variant: dict(name, ms, flops, launches) for variants that were launched."""
     out = []
-    for v in range(16):
+    for v in range(32):
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         check(dll().vitk_gemm_profile_read(v, C.byref(ms), C.byref(fl), C.byref(n), 0))
         if n.value:
