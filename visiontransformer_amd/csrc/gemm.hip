@@ -436,6 +436,7 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     // six slabs per trip = both register sets x all three ring slots: every LDS address in here is
     // a loop-invariant register plus a literal, so the trip carries no address arithmetic (vector
     // instructions do not overlap with fp32 MFMAs, they take their place)
+    if constexpr (FULL)  // (the guarded kernels have no registers to spare for it)
     for (; t + 9 < nslab; t += 6) {
       VITK_SLAB(t, ra0, rb0, true, 0, VITK_STAGE_LIT)
       VITK_SLAB(t + 1, ra1, rb1, true, 1, VITK_STAGE_LIT)
