@@ -506,6 +506,21 @@ def test_gemm_ragged_contraction_of_a_weight_gradient(K, Kd, split):
     close(host(dw), x.astype(np.float64).T @ dy.astype(np.float64), 1e-5)
     close(host(bias), dy.astype(np.float64).sum(0), 1e-5)
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_every_slab_count_through_prologue_unrolled_loop_and_tail(K, ta, tb):
+    """K = 16 .. 25 slabs of 16 (+ a ragged one where the layout allows): the unguarded kernel runs
+    a straight-line prologue, a loop unrolled six slabs deep and a guarded tail; every split of a
+    contraction between the three must give the same product."""
+    M, N = 256, 128
+    for nslab in list(range(1, 26)) + [31, 48]:
+        for extra in ((0, 5) if (ta and not tb) else (0,)):
+            Kd = 16 * nslab + extra
+            a = V.rng_normal(100 + nslab, *((Kd, M) if ta else (M, Kd)))
+            b = V.rng_normal(200 + nslab, *((N, Kd) if tb else (Kd, N)))
+            c = empty(M, N)
+            K.gemm(dev(a), dev(b), c, M, N, Kd, trans_a=bool(ta), trans_b=bool(tb))
+            close(host(c), ref_gemm(a, b, ta, tb), 1e-5)
+
 def test_gather_rows_assembles_a_shuffled_batch(K):
     src = V.rng_normal(3, 50, 37)
     idx = np.random.default_rng(4).permutation(50)[:21].astype(np.int32)
