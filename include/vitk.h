@@ -126,6 +126,21 @@ int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const
                        int64_t rows, int64_t D, int64_t row_stride, const float *residual, float *dx, float *dgamma,
                        float *dbeta, float *workspace, size_t workspace_bytes, vitk_stream_t stream);
 
+/* vitk_layernorm_bwd for callers that cannot allocate or pass a workspace.  It has no counterpart
+ * in the reference; it exists for callers that must not call hipMalloc: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation.  Same arithmetic, kernels and
+ * results (bit for bit) as vitk_layernorm_bwd, but the per-workgroup dgamma/dbeta partials live
+ * in a fixed 8 MiB array inside the library's device code (one copy per GPU, held until the
+ * process ends) instead of a workspace: no hipMalloc/hipFree, no allocating call of any kind.
+ * Limit: D <= vitk_layernorm_bwd_static_max_d() (1024); larger D is rejected with an error.
+ * vitk_init(device) resolves the array's address for that device; without it the first call on
+ * a device does (one hipGetSymbolAddress).  All calls on one GPU share the array: calls that
+ * overlap on one GPU (different streams or threads) race -- serialise them. */
+size_t vitk_layernorm_bwd_static_max_d(void);
+int vitk_layernorm_bwd_static(const float *dy, const float *x, const float *mean, const float *inv_std,
+                              const float *gamma, int64_t rows, int64_t D, int64_t row_stride, const float *residual,
+                              float *dx, float *dgamma, float *dbeta, vitk_stream_t stream);
+
 /* ---- GELU, tanh approximation (src/activations/GELU.cpp:9,13-42,44-81) ------------------------ */
 int vitk_gelu_fwd(const float *x, int64_t n, float *y, vitk_stream_t stream);
 int vitk_gelu_bwd(const float *x, const float *dy, int64_t n, float *dx, vitk_stream_t stream);

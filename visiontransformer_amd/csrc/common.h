@@ -17,6 +17,10 @@ inline hipStream_t as_stream(vitk_stream_t s) { return reinterpret_cast<hipStrea
 // Checks the launch that has just been enqueued; returns 0 or records the error.
 int check_launch(const char *what);
 
+// Caches the current device's address of the scratch array behind vitk_layernorm_bwd_static
+// (norm.hip); called by vitk_init.
+int norm_static_setup();
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kWave = 64;

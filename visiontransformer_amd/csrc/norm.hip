@@ -4,6 +4,8 @@
 #pragma clang fp contract(off)
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int TPB = 256;
@@ -281,7 +283,52 @@ bool ln_vec_ok(const void *a, const void *b, const void *c, const void *d, long 
          vitk::aligned16(c) && vitk::aligned16(d);
 }
 
+// ---- scratch of the entry point that allocates nothing -----------------------------------------
+// vitk_layernorm_bwd_static keeps the per-workgroup [dgamma | dbeta] partials in this array instead
+// of a caller-provided workspace: ln_blocks() <= 1024 workgroups x 2 x D floats, D <= kStaticMaxD.
+// Every device that loads this code object holds its own 8 MiB copy until the process ends.
+constexpr long long kStaticMaxD = 1024;
+constexpr long long kStaticFloats = 1024ll * 2 * kStaticMaxD;
+constexpr int kMaxDevices = 64;
+
+// Device address of `scratch` on each device, filled by static_scratch() with that device current.
+// The array's name itself is only a host-side handle for hipGetSymbolAddress.
+float *g_static_ptr[kMaxDevices] = {};
+std::mutex g_static_mutex;
+
 }  // namespace
+
+static __device__ __align__(256) float scratch[kStaticFloats];
+
+namespace {
+
+// Looks the array up once per device (the calling thread's current device) and caches the address.
+int static_scratch(float **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  VITK_REQUIRE(e == hipSuccess, "vitk_layernorm_bwd_static: hipGetDevice: %s", hipGetErrorString(e));
+  VITK_REQUIRE(dev >= 0 && dev < kMaxDevices, "vitk_layernorm_bwd_static: device %d beyond the %d supported", dev,
+               kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (!g_static_ptr[dev]) {
+    float *p = nullptr;
+    e = hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch));
+    VITK_REQUIRE(e == hipSuccess && p != nullptr, "vitk_layernorm_bwd_static: hipGetSymbolAddress on device %d: %s",
+                 dev, hipGetErrorString(e));
+    g_static_ptr[dev] = p;
+  }
+  *out = g_static_ptr[dev];
+  return 0;
+}
+
+}  // namespace
+
+namespace vitk {
+int norm_static_setup() {
+  float *p;
+  return static_scratch(&p);
+}
+}  // namespace vitk
 
 extern "C" {
 
@@ -385,6 +432,25 @@ int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const
   hipLaunchKernelGGL(reduce_partials_kernel, rg, dim3(RED_COLS * RED_WAVES), 0, st, workspace, nblk,
                      (long long)(2 * D), (long long)(2 * D), (long long)D, dgamma, dbeta);
   return vitk::check_launch("vitk_layernorm_bwd/final");
+}
+
+size_t vitk_layernorm_bwd_static_max_d(void) { return (size_t)kStaticMaxD; }
+
+int vitk_layernorm_bwd_static(const float *dy, const float *x, const float *mean, const float *inv_std,
+                              const float *gamma, int64_t rows, int64_t D, int64_t row_stride, const float *residual,
+                              float *dx, float *dgamma, float *dbeta, vitk_stream_t stream) {
+  VITK_REQUIRE(D > 0 && D <= kStaticMaxD, "vitk_layernorm_bwd_static: D = %lld is beyond the built-in scratch (D <= %lld)",
+               (long long)D, kStaticMaxD);
+  VITK_REQUIRE(rows >= 0, "vitk_layernorm_bwd_static: bad shape");
+  const size_t need = vitk_layernorm_bwd_workspace_bytes(rows, D);
+  VITK_REQUIRE(need <= (size_t)kStaticFloats * sizeof(float),
+               "vitk_layernorm_bwd_static: %zu bytes of partials exceed the built-in scratch", need);
+  float *ws = nullptr;
+  if (static_scratch(&ws)) return 1;
+  // Every partial the second stage reads is written by the first stage of this same call, so the
+  // previous call's contents need no clearing.
+  return vitk_layernorm_bwd(dy, x, mean, inv_std, gamma, rows, D, row_stride, residual, dx, dgamma, dbeta, ws,
+                            (size_t)kStaticFloats * sizeof(float), stream);
 }
 
 }  // extern "C"

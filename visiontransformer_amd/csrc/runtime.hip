@@ -43,7 +43,9 @@ int vitk_init(int device) {
   VITK_REQUIRE(e == hipSuccess, "vitk_init: hipGetDeviceProperties: %s", hipGetErrorString(e));
   VITK_REQUIRE(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0,
                "vitk_init: device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
-  return 0;
+  // resolve this device's copy of the built-in scratch now, so that vitk_layernorm_bwd_static makes
+  // no runtime query later (e.g. under stream capture)
+  return vitk::norm_static_setup();
 }
 
 }  // extern "C"
