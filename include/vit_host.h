@@ -35,6 +35,19 @@ int vith_set_stream(void *hip_stream);
 int vith_synchronize(void);
 /* seeds weight initialisation, data subsampling and dropout (the reference uses random_device) */
 int vith_seed(uint64_t seed);
+/* Dropout draws (src/layers/Dropout.cpp:42-51).  The reference seeds each mask from random_device;
+ * here the factors of a Dropout forward over n elements are a pure function of (seed, offset,
+ * element index) -- the mask vitk_dropout_fwd produces for the same (rate, seed, offset) -- and the
+ * forward then advances offset by ceil(n/4).  vith_dropout_state reads the position the NEXT
+ * dropout forward will use; vith_set_dropout_state moves it (vith_seed resets it).
+ * vith_dropout_replay: while set, every training-mode Dropout forward takes its n factors
+ * (0 or 1/(1-rate)) from masks_dev in call order instead -- per encoder block the attention-branch
+ * mask, then the feed-forward mask (src/model/TransformerEncoderBlock.cpp:23, src/layers/
+ * FeedForward.cpp:22) -- which repeats a run whose masks were recorded from the reference.
+ * count = floats available; NULL / 0 ends the replay; the buffer must outlive the backward pass. */
+int vith_dropout_state(uint64_t *seed, uint64_t *offset);
+int vith_set_dropout_state(uint64_t seed, uint64_t offset);
+int vith_dropout_replay(const float *masks_dev, uint64_t count);
 /* Attention path of layers / models created AFTERWARDS: 1 (default) = the fused kernels
  * (vitk_sdpa_fwd / vitk_sdpa_bwd) where the shape is supported, 0 = batched contractions + row
  * softmax with the probabilities materialised (the reference's own sequence of operations,
@@ -145,6 +158,8 @@ int vith_epoch_order(uint64_t n, int32_t epoch, uint64_t *order_host);
  *       6 Embeddings(a=image,b=patch,c=channels,d=D) */
 typedef void *vith_layer;
 vith_layer vith_layer_create(int kind, uint64_t a, uint64_t b, uint64_t c, uint64_t d);
+/* the same with a dropout rate for the kinds that take one (4 FeedForward, 5 TransformerEncoderBlock) */
+vith_layer vith_layer_create_dropout(int kind, uint64_t a, uint64_t b, uint64_t c, uint64_t d, float dropout_rate);
 void vith_layer_destroy(vith_layer l);
 uint64_t vith_layer_param_count(vith_layer l);
 int vith_layer_set_params(vith_layer l, const float *flat_host);

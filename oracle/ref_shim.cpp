@@ -9,7 +9,8 @@
 // Nothing here restates reference arithmetic: every number comes out of the
 // reference's Tensor / Layer / Loss / Optimizer objects.  The private-member
 // access below is only used to read intermediate activations out of
-// VisionTransformer (include/model/VisionTransformer.hpp:108-121).
+// VisionTransformer (include/model/VisionTransformer.hpp:108-121) and the masks
+// its Dropout layers drew (include/layers/Dropout.hpp:60).
 #include <cstdint>
 #include <cstring>
 #include <random>
@@ -358,6 +359,39 @@ void vref_block(uint64_t D, uint64_t h, uint64_t H, const float *params, const f
     Tensor gx = L.backward(make({B, N, D}, dy));
     get_flat(L.getGradients(), grads);
     dump(gx, dx);
+  }
+}
+
+// The masks the block's two Dropout layers drew in their last training forward
+// (attention_dropout, then ffn.dropout): 2 x {B*N*D}.  The reference draws them from a
+// random_device-seeded engine (src/layers/Dropout.cpp:31-33); reading them back is the only way
+// to know which elements a given run dropped.
+static void dump_block_masks(TransformerEncoderBlock &blk, float *dst, size_t n) {
+  dump(blk.attention_dropout.mask, dst);
+  dump(blk.ffn.dropout.mask, dst + n);
+}
+
+// TransformerEncoderBlock at dropout `rate` (> 0): as vref_block, plus the drawn masks.
+void vref_block_dropout(uint64_t D, uint64_t h, uint64_t H, float rate, const float *params, const float *x, uint64_t B,
+                        uint64_t N, const float *dy, float *y, float *grads, float *dx, float *masks) {
+  TransformerEncoderBlock L(D, h, H, rate);
+  set_flat(L.getParameters(), params);
+  dump(L.forward(make({B, N, D}, x), true), y);
+  dump_block_masks(L, masks, B * N * D);
+  if (dy) {
+    Tensor gx = L.backward(make({B, N, D}, dy));
+    get_flat(L.getGradients(), grads);
+    dump(gx, dx);
+  }
+}
+
+// Masks of every block after a training-mode forward of the session's model: L x 2 x {B*N*D}.
+void vref_get_dropout_masks(void *s, uint64_t B, float *masks) {
+  auto *S = static_cast<Session *>(s);
+  const size_t n = B * S->model.num_tokens * S->cfg.embedding_dim;
+  for (auto &blk : S->model.encoder_blocks) {
+    dump_block_masks(blk, masks, n);
+    masks += 2 * n;
   }
 }
 

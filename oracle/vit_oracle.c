@@ -291,9 +291,16 @@ typedef struct {
   float *pre, *act;
 } ffn_cache;
 
-/* FeedForward::forward, src/layers/FeedForward.cpp:18-24 (dropout rate 0 => identity,
- * src/layers/Dropout.cpp:23). */
-static void ffn_forward(uint64_t D, uint64_t H, const float *prm, const float *x, uint64_t M, float *y, ffn_cache *c) {
+/* Dropout::forward with the mask given instead of drawn, src/layers/Dropout.cpp:42-51: the mask
+ * holds 0 or 1/(1-rate); a dropped element is written as +0, a kept one as in*scale. */
+static void dropout_apply(float *x, const float *mask, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) x[i] = mask[i] == 0.0f ? 0.0f : x[i] * mask[i];
+}
+
+/* FeedForward::forward, src/layers/FeedForward.cpp:18-24.  mask == NULL: dropout rate 0 or
+ * inference (identity, src/layers/Dropout.cpp:23); otherwise the {M,D} mask of its Dropout. */
+static void ffn_forward(uint64_t D, uint64_t H, const float *prm, const float *x, uint64_t M, const float *mask,
+                        float *y, ffn_cache *c) {
   const float *W1 = prm, *b1 = W1 + D * H, *W2 = b1 + H, *b2 = W2 + H * D;
   c->x = x;
   c->pre = falloc(M * H);
@@ -301,10 +308,12 @@ static void ffn_forward(uint64_t D, uint64_t H, const float *prm, const float *x
   vo_dense_forward(x, M, D, H, W1, b1, c->pre);
   vo_gelu_forward(c->pre, M * H, c->act);
   vo_dense_forward(c->act, M, H, D, W2, b2, y);
+  if (mask) dropout_apply(y, mask, M * D);
 }
 
 /* FeedForward::backward, src/layers/FeedForward.cpp:29-35: dense2.backward receives the
- * ORIGINAL outputGradient (the dropout-masked gradient is discarded). */
+ * ORIGINAL outputGradient (the dropout-masked gradient is computed on line 30 and discarded on
+ * line 31), so the mask does not appear here at any dropout rate. */
 static void ffn_backward(uint64_t D, uint64_t H, const float *prm, const ffn_cache *c, uint64_t M, const float *dy,
                          float *g, float *dx) {
   const float *W1 = prm, *W2 = W1 + D * H + H;
@@ -319,7 +328,7 @@ static void ffn_backward(uint64_t D, uint64_t H, const float *prm, const ffn_cac
 void vo_ffn(uint64_t D, uint64_t H, const float *params, const float *x, uint64_t B, uint64_t N, const float *dy,
             float *y, float *grads, float *dx) {
   ffn_cache c;
-  ffn_forward(D, H, params, x, B * N, y, &c);
+  ffn_forward(D, H, params, x, B * N, NULL, y, &c);
   if (dy) ffn_backward(D, H, params, &c, B * N, dy, grads, dx);
   free(c.pre); free(c.act);
 }
@@ -332,9 +341,11 @@ typedef struct {
 
 static uint64_t block_params(uint64_t D, uint64_t H) { return 2 * D + 4 * (D * D + D) + 2 * D + (D * H + H) + (H * D + D); }
 
-/* TransformerEncoderBlock::forward, src/model/TransformerEncoderBlock.cpp:14-35 (pre-norm). */
+/* TransformerEncoderBlock::forward, src/model/TransformerEncoderBlock.cpp:14-35 (pre-norm).
+ * masks == NULL: no dropout.  Otherwise 2 x {M,D}: the mask of attention_dropout (:23), then the
+ * mask of the FeedForward's dropout (src/layers/FeedForward.cpp:22). */
 static void block_forward(uint64_t D, uint64_t h, uint64_t H, const float *prm, const float *x, uint64_t B, uint64_t N,
-                          float *y, block_cache *c) {
+                          const float *masks, float *y, block_cache *c) {
   const uint64_t M = B * N;
   const float *g1 = prm, *b1 = g1 + D, *mha = b1 + D, *g2 = mha + 4 * (D * D + D), *b2 = g2 + D, *ffn = b2 + D;
   c->xhat1 = falloc(M * D); c->inv1 = falloc(M); c->n1 = falloc(M * D);
@@ -343,16 +354,19 @@ static void block_forward(uint64_t D, uint64_t h, uint64_t H, const float *prm, 
   float *t = falloc(M * D);
   vo_layernorm_forward(x, M, D, g1, b1, 1e-5f, c->n1, c->xhat1, c->inv1);
   mha_forward(D, h, mha, c->n1, B, N, t, &c->mha);
+  if (masks) dropout_apply(t, masks, M * D);
   for (uint64_t i = 0; i < M * D; ++i) c->res1[i] = x[i] + t[i];
   vo_layernorm_forward(c->res1, M, D, g2, b2, 1e-5f, c->n2, c->xhat2, c->inv2);
-  ffn_forward(D, H, ffn, c->n2, M, t, &c->ffn);
+  ffn_forward(D, H, ffn, c->n2, M, masks ? masks + M * D : NULL, t, &c->ffn);
   for (uint64_t i = 0; i < M * D; ++i) y[i] = c->res1[i] + t[i];
   free(t);
 }
 
-/* TransformerEncoderBlock::backward, src/model/TransformerEncoderBlock.cpp:40-64. */
+/* TransformerEncoderBlock::backward, src/model/TransformerEncoderBlock.cpp:40-64.  The attention
+ * branch multiplies by its dropout mask (:58, Dropout::backward src/layers/Dropout.cpp:79-81); the
+ * feed-forward branch does not (see ffn_backward). */
 static void block_backward(uint64_t D, uint64_t h, uint64_t H, const float *prm, const block_cache *c, uint64_t B,
-                           uint64_t N, const float *dy, float *g, float *dx) {
+                           uint64_t N, const float *masks, const float *dy, float *g, float *dx) {
   const uint64_t M = B * N;
   const float *g1 = prm, *mha = g1 + 2 * D, *g2 = mha + 4 * (D * D + D), *ffn = g2 + 2 * D;
   float *dg1 = g, *dmha = dg1 + 2 * D, *dg2 = dmha + 4 * (D * D + D), *dffn = dg2 + 2 * D;
@@ -360,7 +374,15 @@ static void block_backward(uint64_t D, uint64_t h, uint64_t H, const float *prm,
   ffn_backward(D, H, ffn, &c->ffn, M, dy, dffn, t);
   vo_layernorm_backward(t, c->xhat2, c->inv2, g2, M, D, dg2, dg2 + D, u);
   for (uint64_t i = 0; i < M * D; ++i) grad1[i] = dy[i] + u[i];
-  mha_backward(D, h, mha, &c->mha, B, N, grad1, dmha, t);
+  const float *gm = grad1;
+  float *masked = NULL;
+  if (masks) {
+    masked = falloc(M * D);
+    for (uint64_t i = 0; i < M * D; ++i) masked[i] = grad1[i] * masks[i];
+    gm = masked;
+  }
+  mha_backward(D, h, mha, &c->mha, B, N, gm, dmha, t);
+  free(masked);
   vo_layernorm_backward(t, c->xhat1, c->inv1, g1, M, D, dg1, dg1 + D, u);
   for (uint64_t i = 0; i < M * D; ++i) dx[i] = grad1[i] + u[i];
   free(t); free(u); free(grad1);
@@ -372,12 +394,17 @@ static void block_cache_free(block_cache *c) {
   free(c->ffn.pre); free(c->ffn.act);
 }
 
+void vo_block_masked(uint64_t D, uint64_t h, uint64_t H, const float *params, const float *x, uint64_t B, uint64_t N,
+                     const float *masks, const float *dy, float *y, float *grads, float *dx) {
+  block_cache c;
+  block_forward(D, h, H, params, x, B, N, masks, y, &c);
+  if (dy) block_backward(D, h, H, params, &c, B, N, masks, dy, grads, dx);
+  block_cache_free(&c);
+}
+
 void vo_block(uint64_t D, uint64_t h, uint64_t H, const float *params, const float *x, uint64_t B, uint64_t N,
               const float *dy, float *y, float *grads, float *dx) {
-  block_cache c;
-  block_forward(D, h, H, params, x, B, N, y, &c);
-  if (dy) block_backward(D, h, H, params, &c, B, N, dy, grads, dx);
-  block_cache_free(&c);
+  vo_block_masked(D, h, H, params, x, B, N, NULL, dy, y, grads, dx);
 }
 
 /* PatchEmbedding::forward gather, src/layers/PatchEmbedding.cpp:31-52.  NOT an im2col: for
@@ -664,8 +691,8 @@ typedef struct {
 } model_cache;
 
 /* VisionTransformer::forward, src/model/VisionTransformer.cpp:20-38. */
-static void model_forward(const vo_cfg *c, const float *prm, const float *x, uint64_t B, float *logits,
-                          model_cache *mc) {
+static void model_forward(const vo_cfg *c, const float *prm, const float *x, uint64_t B, const float *masks,
+                          float *logits, model_cache *mc) {
   const uint64_t D = c->embedding_dim, H = c->mlp_hidden_dim, L = c->num_layers, N = tokens(c), M = B * N,
                  K = c->num_classes;
   const float *emb = prm, *blk0 = emb + emb_params(c), *fn = blk0 + L * block_params(D, H), *head = fn + 2 * D;
@@ -676,7 +703,8 @@ static void model_forward(const vo_cfg *c, const float *prm, const float *x, uin
   const float *cur = mc->emb;
   for (uint64_t l = 0; l < L; ++l) {
     mc->blk_out[l] = falloc(M * D);
-    block_forward(D, c->num_heads, H, blk0 + l * block_params(D, H), cur, B, N, mc->blk_out[l], &mc->blk[l]);
+    block_forward(D, c->num_heads, H, blk0 + l * block_params(D, H), cur, B, N,
+                  masks ? masks + l * 2 * M * D : NULL, mc->blk_out[l], &mc->blk[l]);
     cur = mc->blk_out[l];
   }
   mc->fxhat = falloc(M * D); mc->finv = falloc(M); mc->fnorm = falloc(M * D);
@@ -687,8 +715,8 @@ static void model_forward(const vo_cfg *c, const float *prm, const float *x, uin
 }
 
 /* VisionTransformer::backward, src/model/VisionTransformer.cpp:43-69. */
-static void model_backward(const vo_cfg *c, const float *prm, const model_cache *mc, uint64_t B, const float *dlogits,
-                           float *g, float *dacts) {
+static void model_backward(const vo_cfg *c, const float *prm, const model_cache *mc, uint64_t B, const float *masks,
+                           const float *dlogits, float *g, float *dacts) {
   const uint64_t D = c->embedding_dim, H = c->mlp_hidden_dim, L = c->num_layers, N = tokens(c), M = B * N,
                  K = c->num_classes, bp = block_params(D, H);
   const float *blk0 = prm + emb_params(c), *fn = blk0 + L * bp, *head = fn + 2 * D;
@@ -700,7 +728,8 @@ static void model_backward(const vo_cfg *c, const float *prm, const model_cache 
   vo_layernorm_backward(grad_seq, mc->fxhat, mc->finv, fn, M, D, gfn, gfn + D, grad);
   if (dacts) { memcpy(dacts, grad, M * D * sizeof(float)); dacts += M * D; }
   for (int64_t l = (int64_t)L - 1; l >= 0; --l) {
-    block_backward(D, c->num_heads, H, blk0 + l * bp, &mc->blk[l], B, N, grad, gblk0 + l * bp, next);
+    block_backward(D, c->num_heads, H, blk0 + l * bp, &mc->blk[l], B, N, masks ? masks + l * 2 * M * D : NULL, grad,
+                   gblk0 + l * bp, next);
     float *t = grad; grad = next; next = t;
     if (dacts) { memcpy(dacts, grad, M * D * sizeof(float)); dacts += M * D; }
   }
@@ -724,24 +753,31 @@ static void copy_acts(const vo_cfg *c, const model_cache *mc, uint64_t B, float 
 
 void vo_forward(const vo_cfg *c, const float *params, const float *x, uint64_t B, float *logits, float *acts) {
   model_cache mc;
-  model_forward(c, params, x, B, logits, &mc);
+  model_forward(c, params, x, B, NULL, logits, &mc);
   if (acts) copy_acts(c, &mc, B, acts);
   model_cache_free(c, &mc);
 }
 
-float vo_forward_backward(const vo_cfg *c, const float *params, const float *x, const float *y, uint64_t B,
-                          const float *class_w, uint64_t n_w, float *logits, float *grads, float *dacts) {
+float vo_forward_backward_masked(const vo_cfg *c, const float *params, const float *x, const float *y, uint64_t B,
+                                 const float *class_w, uint64_t n_w, const float *masks, float *logits, float *grads,
+                                 float *acts, float *dacts) {
   model_cache mc;
   const uint64_t K = c->num_classes;
   float *lg = logits ? logits : falloc(B * K);
   float *dl = falloc(B * K);
-  model_forward(c, params, x, B, lg, &mc);
+  model_forward(c, params, x, B, masks, lg, &mc);
+  if (acts) copy_acts(c, &mc, B, acts);
   float loss = vo_cross_entropy(lg, y, B, K, class_w, n_w, dl);
-  model_backward(c, params, &mc, B, dl, grads, dacts);
+  model_backward(c, params, &mc, B, masks, dl, grads, dacts);
   model_cache_free(c, &mc);
   free(dl);
   if (!logits) free(lg);
   return loss;
+}
+
+float vo_forward_backward(const vo_cfg *c, const float *params, const float *x, const float *y, uint64_t B,
+                          const float *class_w, uint64_t n_w, float *logits, float *grads, float *dacts) {
+  return vo_forward_backward_masked(c, params, x, y, B, class_w, n_w, NULL, logits, grads, NULL, dacts);
 }
 
 typedef struct {
@@ -777,10 +813,17 @@ void vo_session_set_class_weights(void *h, const float *w, uint64_t n) {
 
 /* Body of Trainer::train_epoch after batching (src/model/Trainer.cpp:201-227) with Adam::update
  * (src/optimizers/Adam.cpp:29-33: t++, beta^t via double pow cast to float). */
+float vo_session_train_step_masked(void *h, const float *x, const float *y, uint64_t B, float lr_now,
+                                   const float *masks, float *logits_out, float *grads_out);
 float vo_session_train_step(void *h, const float *x, const float *y, uint64_t B, float lr_now, float *logits_out,
                             float *grads_out) {
+  return vo_session_train_step_masked(h, x, y, B, lr_now, NULL, logits_out, grads_out);
+}
+
+float vo_session_train_step_masked(void *h, const float *x, const float *y, uint64_t B, float lr_now,
+                                   const float *masks, float *logits_out, float *grads_out) {
   session *s = (session *)h;
-  float loss = vo_forward_backward(&s->cfg, s->p, x, y, B, s->cw, s->n_cw, logits_out, s->g, NULL);
+  float loss = vo_forward_backward_masked(&s->cfg, s->p, x, y, B, s->cw, s->n_cw, masks, logits_out, s->g, NULL, NULL);
   if (grads_out) memcpy(grads_out, s->g, s->n * sizeof(float));
   s->t++;
   const float b1t = (float)pow((double)s->beta1, (double)s->t);

@@ -23,7 +23,8 @@ extern "C" {
 
 typedef struct {
   uint64_t image_size, patch_size, in_channels, num_classes, embedding_dim, num_heads, num_layers, mlp_hidden_dim;
-  float dropout_rate; /* must be 0 for the oracle: the reference's dropout is seeded from random_device */
+  float dropout_rate; /* informational: the oracle never draws dropout masks (the reference seeds them from
+                       * random_device); dropout is applied only by the *_masked entry points, from given masks */
 } vo_cfg;
 
 /* ---- free functions (src/core/Tensor.cpp) ---- */
@@ -50,6 +51,13 @@ void vo_ffn(uint64_t D, uint64_t H, const float *params, const float *x, uint64_
             float *y, float *grads, float *dx);
 void vo_block(uint64_t D, uint64_t h, uint64_t H, const float *params, const float *x, uint64_t B, uint64_t N,
               const float *dy, float *y, float *grads, float *dx);
+/* vo_block with dropout at a given draw: masks = 2 x {B*N,D} holding 0 or 1/(1-rate) -- the mask of
+ * the block's attention_dropout (src/model/TransformerEncoderBlock.cpp:23), then the mask of its
+ * FeedForward's dropout (src/layers/FeedForward.cpp:22).  The backward applies the first mask on the
+ * attention branch (:58) and none on the feed-forward branch (src/layers/FeedForward.cpp:30-31).
+ * masks == NULL is vo_block. */
+void vo_block_masked(uint64_t D, uint64_t h, uint64_t H, const float *params, const float *x, uint64_t B, uint64_t N,
+                     const float *masks, const float *dy, float *y, float *grads, float *dx);
 void vo_patch_gather(const float *img, uint64_t B, uint64_t C, uint64_t HW, uint64_t P, float *patches);
 void vo_embeddings(uint64_t img, uint64_t P, uint64_t C, uint64_t D, const float *params, const float *x, uint64_t B,
                    const float *dy, float *y, float *grads);
@@ -87,6 +95,12 @@ void vo_forward(const vo_cfg *c, const float *params, const float *x, uint64_t B
 float vo_forward_backward(const vo_cfg *c, const float *params, const float *x, const float *y, uint64_t B,
                           const float *class_w, uint64_t n_w, float *logits, float *grads, float *dacts);
 
+/* The same with dropout at a given draw: masks = L x 2 x {B*N,D} (per block as vo_block_masked), or
+ * NULL.  acts (optional) as in vo_forward. */
+float vo_forward_backward_masked(const vo_cfg *c, const float *params, const float *x, const float *y, uint64_t B,
+                                 const float *class_w, uint64_t n_w, const float *masks, float *logits, float *grads,
+                                 float *acts, float *dacts);
+
 /* session = params + Adam state + step counter, to run the Trainer's per-batch body */
 void *vo_session_create(const vo_cfg *c, float beta1, float beta2, float eps, float wd);
 void vo_session_destroy(void *s);
@@ -95,6 +109,8 @@ void vo_session_get_params(void *s, float *flat);
 void vo_session_set_class_weights(void *s, const float *w, uint64_t n);
 float vo_session_train_step(void *s, const float *x, const float *y, uint64_t B, float lr_now, float *logits_out,
                             float *grads_out);
+float vo_session_train_step_masked(void *s, const float *x, const float *y, uint64_t B, float lr_now,
+                                   const float *masks, float *logits_out, float *grads_out);
 
 #ifdef __cplusplus
 }

@@ -196,12 +196,64 @@ def augment():
     np.savez_compressed(os.path.join(G, "augment.npz"), **out)
 
 
+def dropout():
+    """The reference at dropout 0.2 (its own default, app/main.cpp:19).  Its masks come from a
+    random_device-seeded engine, so each run below is unrepeatable; the masks it drew are read
+    back (vref_block_dropout / vref_get_dropout_masks) and stored, one bit per element, next to
+    what it computed with them."""
+    out = {}
+    c = V.dropout_block_case()
+    D, H, h, B, N, rate = c["D"], c["H"], c["h"], c["B"], c["N"], c["rate"]
+    y, g_, dx, masks = V.f32(B, N, D), V.f32(c["n"]), V.f32(B, N, D), V.f32(2, B * N * D)
+    R.vref_block_dropout(D, h, H, rate, c["prm"], c["x"], B, N, c["dy"], y, g_, dx, masks)
+    out.update(block_y=y, block_g=g_, block_dx=dx, block_masks=V.pack_masks(masks))
+
+    cfgd, B, seed, steps = V.DROPOUT_MODEL_CASE
+    c = V.model_case_inputs(cfgd, B, seed, steps)
+    cfg, prm, w, x, y = c["cfg"], c["prm"], c["w"], c["x"], c["y"]
+    K, L, N, D = cfg.num_classes, cfg.num_layers, cfg.tokens, cfg.embedding_dim
+    shapes = V.param_shapes(cfg)
+    n = len(prm)
+    s = R.vref_create(cfg, 3e-4, 0.9, 0.999, 1e-8, 1e-4)
+    R.vref_set_params(s, prm)
+    R.vref_set_class_weights(s, w, K)
+    acts, lg, masks = V.f32(L + 2, B, N, D), V.f32(B, K), V.f32(L, 2, B * N * D)
+    R.vref_forward_trace(s, x, B, acts, lg)
+    R.vref_get_dropout_masks(s, B, masks)
+    dl = V.f32(B, K)
+    out["model_loss"] = np.float32(R.vref_cross_entropy(lg, y, B, K, w, K, dl))
+    dacts = V.f32(L + 1, B, N, D)
+    R.vref_backward_trace(s, dl, B, dacts)
+    g = V.f32(n)
+    R.vref_get_grads(s, g)
+    gs, gn, gsm = V.tensor_digest(g, shapes)
+    out.update(model_acts=acts, model_logits=lg.copy(), model_dlogits=dl, model_dacts=dacts,
+               model_masks=V.pack_masks(masks), grad_sums=gs, grad_norms=gn, grad_samples=gsm)
+    losses, step_masks = [], []
+    for t in range(steps):
+        lr = R.vref_cosine_warmup_lr(t + 1, 2, steps + 2, 3e-4)
+        losses.append(R.vref_train_step(s, c["xs"][t], c["ys"][t], B, lr, lg, None))
+        R.vref_get_dropout_masks(s, B, masks)
+        step_masks.append(V.pack_masks(masks))
+    p2 = V.f32(n)
+    R.vref_get_params(s, p2)
+    ps, pn, psm = V.tensor_digest(p2, shapes)
+    out.update(step_losses=np.array(losses, np.float32), step_masks=np.stack(step_masks), p_sums=ps, p_norms=pn,
+               p_samples=psm)
+    R.vref_destroy(s)
+    np.savez_compressed(os.path.join(G, "dropout.npz"), **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["augment"]:
         augment()
         sys.exit(0)
+    if sys.argv[1:] == ["dropout"]:
+        dropout()
+        sys.exit(0)
     ops()
     augment()
+    dropout()
     for name, (cfgd, B, seed, steps, full) in V.MODEL_CASES.items():
         model_case(name, cfgd, B, seed, steps, full)
     shipped_checkpoint()

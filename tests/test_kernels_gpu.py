@@ -41,11 +41,7 @@ def empty(*shape):
 
 
 def close(got, want, tol, floor=None):
-    got, want = np.asarray(got), np.asarray(want)
-    assert got.shape == want.shape, (got.shape, want.shape)
-    assert np.isfinite(got).all()
-    e = V.max_relerr(got, want, floor)
-    assert e <= tol, f"max rel err {e:.3e} > {tol:.1e}"
+    V.assert_close(got, want, tol, "", floor)
 
 
 # ----------------------------------------------------------------------------------- GEMM
@@ -213,14 +209,17 @@ def test_gelu_vs_oracle(K, n):
     Y, DX = empty(n), empty(n)
     K.call("vitk_gelu_fwd", dev(x), n, Y, K.stream())
     K.call("vitk_gelu_bwd", dev(x), dev(dy), n, DX, K.stream())
-    close(host(Y), y, 2e-6)
-    close(host(DX), dx, 2e-6)
+    # the logistic form x / (1 + e^(-2u)) against the reference's 0.5 x (1 + tanh u) in float:
+    # 2e-6 of the largest output, and per element 3e-6 (of |value| + rms)
+    assert V.max_relerr(host(Y), y) <= 2e-6 and V.max_relerr(host(DX), dx) <= 2e-6
+    close(host(Y), y, 3e-6)
+    close(host(DX), dx, 3e-6)
     if n == 2048:
         g = V.golden("ops.npz")
         c = V.op_case("gelu")
         K.call("vitk_gelu_fwd", dev(c["x"]), n, Y, K.stream())
         K.call("vitk_gelu_bwd", dev(c["x"]), dev(c["dy"]), n, DX, K.stream())
-        close(host(Y), g["gelu_y"], 2e-6); close(host(DX), g["gelu_dx"], 2e-6)
+        close(host(Y), g["gelu_y"], 3e-6); close(host(DX), g["gelu_dx"], 3e-6)
 
 
 def test_dropout(K):

@@ -172,3 +172,43 @@ def test_augmentation_golden(name):
     o = V.f32(c["B"], c["C"], c["H"], c["W"])
     O.vo_augment(c["x"], c["B"], c["C"], c["H"], c["W"], c["seed"], c["cfg"], o, None)
     np.testing.assert_array_equal(o, V.golden("augment.npz")[name])
+
+
+def test_dropout_golden():
+    """The reference at dropout 0.2 with the masks it drew (tests/golden/dropout.npz): a block and
+    a whole C1 model, forward, backward (attention-branch mask applied, feed-forward mask not,
+    src/layers/FeedForward.cpp:30-31) and two Adam steps."""
+    g = V.golden("dropout.npz")
+    c = V.dropout_block_case()
+    D, H, h, B, N, rate = c["D"], c["H"], c["h"], c["B"], c["N"], c["rate"]
+    masks = V.unpack_masks(g["block_masks"], (2, B * N * D), rate)
+    assert 0.1 < (masks == 0).mean() < 0.3
+    y, g_, dx = V.f32(B, N, D), V.f32(c["n"]), V.f32(B, N, D)
+    O.vo_block_masked(D, h, H, c["prm"], c["x"], B, N, masks, c["dy"], y, g_, dx)
+    close(y, g["block_y"]); close(g_, g["block_g"]); close(dx, g["block_dx"])
+
+    cfgd, B, seed, steps = V.DROPOUT_MODEL_CASE
+    c = V.model_case_inputs(cfgd, B, seed, steps)
+    cfg, K = c["cfg"], c["cfg"].num_classes
+    L, N, D = cfg.num_layers, cfg.tokens, cfg.embedding_dim
+    shapes = V.param_shapes(cfg)
+    n = len(c["prm"])
+    masks = V.unpack_masks(g["model_masks"], (L, 2, B * N * D), cfg.dropout_rate)
+    acts, lg, gr, dacts = V.f32(L + 2, B, N, D), V.f32(B, K), V.f32(n), V.f32(L + 1, B, N, D)
+    loss = O.vo_forward_backward_masked(cfg, c["prm"], c["x"], c["y"], B, c["w"], K, masks, lg, gr, acts, dacts)
+    assert abs(loss - g["model_loss"]) <= 1e-5 * abs(g["model_loss"])
+    close(acts, g["model_acts"]); close(lg, g["model_logits"])
+    for i in range(L + 1):
+        close(dacts[i], g["model_dacts"][i], 2e-5)
+    V.check_digest(gr, shapes, g["grad_sums"], g["grad_norms"], g["grad_samples"], 2e-5, "grad")
+    s = O.vo_session_create(cfg, 0.9, 0.999, 1e-8, 1e-4)
+    O.vo_session_set_params(s, c["prm"]); O.vo_session_set_class_weights(s, c["w"], K)
+    for t in range(steps):
+        lr = O.vo_cosine_warmup_lr(t + 1, 2, steps + 2, 3e-4)
+        masks = V.unpack_masks(g["step_masks"][t], (L, 2, B * N * D), cfg.dropout_rate)
+        lo = O.vo_session_train_step_masked(s, c["xs"][t], c["ys"][t], B, lr, masks, lg, None)
+        assert abs(lo - g["step_losses"][t]) <= 1e-5 * abs(g["step_losses"][t])
+    p = V.f32(n)
+    O.vo_session_get_params(s, p)
+    V.check_digest(p, shapes, g["p_sums"], g["p_norms"], g["p_samples"], 1e-5, "param after Adam")
+    O.vo_session_destroy(s)

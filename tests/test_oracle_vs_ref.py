@@ -257,3 +257,70 @@ def test_augmentation_many_seeds():
         O.vo_augment(c["x"], c["B"], c["C"], c["H"], c["W"], seed, c["cfg"], o, None)
         R.vref_augment(c["x"], c["B"], c["C"], c["H"], c["W"], seed, c["cfg"], r)
         same(o, r)
+
+
+# ------------------------------------------------------------------------------ dropout > 0
+# The reference draws its masks from a random_device-seeded engine (src/layers/Dropout.cpp:31-33),
+# so a run cannot be repeated -- but the masks it drew stay in its Dropout objects.  They are read
+# back and handed to the oracle, which must then reproduce that run: forward with both masks,
+# backward with the attention-branch mask only (src/layers/FeedForward.cpp:30-31 discards the
+# masked gradient; src/model/TransformerEncoderBlock.cpp:58 keeps it).
+def _check_masks(masks, rate):
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    vals = np.unique(masks)
+    assert set(vals.tolist()) <= {0.0, float(scale)}, vals
+    frac = float((masks == 0).mean())
+    assert abs(frac - rate) < 0.05, frac
+
+
+def test_block_with_dropout_matches_reference_given_its_masks():
+    D, H, h, B, N, rate = 64, 160, 8, 3, 5, 0.2
+    n = 4 * D + 4 * (D * D + D) + D * H + H + H * D + D
+    prm = V.rng_normal(4, n, scale=0.1)
+    prm[:D] += 1; prm[2 * D + 4 * (D * D + D):3 * D + 4 * (D * D + D)] += 1
+    x, dy = V.rng_normal(2, B, N, D), V.rng_normal(3, B, N, D)
+    y, g, dx = V.f32(B, N, D), V.f32(n), V.f32(B, N, D)
+    y2, g2, dx2, masks = V.f32(B, N, D), V.f32(n), V.f32(B, N, D), V.f32(2, B * N * D)
+    R.vref_block_dropout(D, h, H, rate, prm, x, B, N, dy, y2, g2, dx2, masks)
+    _check_masks(masks, rate)
+    O.vo_block_masked(D, h, H, prm, x, B, N, masks, dy, y, g, dx)
+    same(y, y2, 2e-6); same(g, g2, 5e-6); same(dx, dx2, 5e-6)
+    # the masks matter: without them (or with the feed-forward mask also applied in the
+    # backward, i.e. the textbook gradient) the result is far from the reference's
+    O.vo_block(D, h, H, prm, x, B, N, dy, y, g, dx)
+    assert V.max_relerr(y, y2) > 1e-2 and V.max_relerr(g, g2) > 1e-2
+
+
+def test_model_with_dropout_matches_reference_given_its_masks():
+    cfg = V.Cfg.make(**dict(V.CONFIGS["C1"], dropout_rate=0.2))
+    B, steps = 4, 3
+    L, N, D, K = cfg.num_layers, cfg.tokens, cfg.embedding_dim, cfg.num_classes
+    n = O.vo_param_count(cfg)
+    prm = V.init_params(cfg, 21)
+    w = np.full(K, 1.0 / K, np.float32)
+    s = R.vref_create(cfg, 3e-4, 0.9, 0.999, 1e-8, 1e-4)
+    R.vref_set_params(s, prm); R.vref_set_class_weights(s, w, K)
+    o = O.vo_session_create(cfg, 0.9, 0.999, 1e-8, 1e-4)
+    O.vo_session_set_params(o, prm); O.vo_session_set_class_weights(o, w, K)
+    shapes = V.param_shapes(cfg)
+    for t in range(steps):
+        x = V.rng_normal(300 + t, B, 1, 28, 28)
+        y = V.onehot(np.random.default_rng(400 + t).integers(0, K, B), K)
+        lr = 3e-4 * (t + 1) / steps
+        lg, lg2, g, g2 = V.f32(B, K), V.f32(B, K), V.f32(n), V.f32(n)
+        masks = V.f32(L, 2, B * N * D)
+        lrf = R.vref_train_step(s, x, y, B, lr, lg2, g2)
+        R.vref_get_dropout_masks(s, B, masks)
+        _check_masks(masks, 0.2)
+        lo = O.vo_session_train_step_masked(o, x, y, B, lr, masks, lg, g)
+        assert abs(lo - lrf) <= 1e-5 * abs(lrf)
+        same(lg, lg2, 1e-5)
+        off = 0
+        for shp in shapes:
+            k = int(np.prod(shp))
+            assert V.max_relerr(g[off:off + k], g2[off:off + k]) <= 2e-5, (t, shp)
+            off += k
+    p1, p2 = V.f32(n), V.f32(n)
+    O.vo_session_get_params(o, p1); R.vref_get_params(s, p2)
+    assert V.max_relerr(p1, p2) <= 1e-5
+    O.vo_session_destroy(o); R.vref_destroy(s)

@@ -106,6 +106,9 @@ _ORACLE_SIGS = {
     "vo_mha": "uuppuupppp>v",
     "vo_ffn": "uuppuupppp>v",
     "vo_block": "uuuppuupppp>v",
+    "vo_block_masked": "uuuppuuppppp>v",
+    "vo_forward_backward_masked": "ppppupuppppp>f",
+    "vo_session_train_step_masked": "Pppufppp>f",
     "vo_patch_gather": "puuuup>v",
     "vo_embeddings": "uuuuppuppp>v",
     "vo_cross_entropy": "ppuupup>f",
@@ -156,6 +159,8 @@ _REF_SIGS = {
     "vref_mha": "uuppuupppp>v",
     "vref_ffn": "uuppuupppp>v",
     "vref_block": "uuuppuupppp>v",
+    "vref_block_dropout": "uuufppuuppppp>v",
+    "vref_get_dropout_masks": "Pup>v",
     "vref_embeddings": "uuuuppupppp>v",
     "vref_cross_entropy": "ppuupup>f",
     "vref_adam": "uuffffuppp>v",
@@ -245,6 +250,31 @@ def max_relerr(a, b, floor=None):
     b = np.asarray(b, dtype=np.float64)
     scale = float(np.max(np.abs(b))) if floor is None else max(float(np.max(np.abs(b))), floor)
     return float(np.max(np.abs(a - b)) / max(scale, 1e-30))
+
+
+def elementwise_excess(a, b, tol, floor=None):
+    """Largest |a-b| / (tol*|b| + tol*rms(b)) over the elements: <= 1 means every element is
+    within tol of its own magnitude plus tol of the tensor's typical (root-mean-square) magnitude.
+    Unlike max_relerr this does not let small elements hide behind the tensor's largest one."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    rms = float(np.sqrt(np.mean(b * b))) if b.size else 0.0
+    if floor is not None:
+        rms = max(rms, floor)
+    bound = tol * np.abs(b) + tol * max(rms, 1e-30)
+    return float(np.max(np.abs(a - b) / bound)) if b.size else 0.0
+
+
+def assert_close(got, want, tol, what="", floor=None):
+    """Both error bounds the parity tests use: the largest error relative to the tensor's largest
+    magnitude (max_relerr) and the per-element bound of elementwise_excess."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), what
+    e = max_relerr(got, want, floor)
+    assert e <= tol, f"{what}: max rel err {e:.3e} > {tol:.1e}"
+    x = elementwise_excess(got, want, tol, floor)
+    assert x <= 1.0, f"{what}: an element is off by {x:.2f} x (tol*|want| + tol*rms(want)), tol {tol:.1e}"
 
 
 # ----------------------------------------------------------------------------- golden helpers
@@ -384,6 +414,36 @@ MODEL_CASES = {  # name -> (config, B, seed, steps, full_grads)
     "c2_b4": (CONFIGS["C2"], 4, 500, 2, False),
     "ck_b4": (CONFIGS["CK"], 4, 600, 2, False),
 }
+
+
+# ---- dropout > 0 (tests/golden/dropout.npz): the reference's masks are stored one bit per element
+DROPOUT_RATE = 0.2  # the reference's training default (app/main.cpp:19)
+DROPOUT_MODEL_CASE = (dict(CONFIGS["C1"], dropout_rate=DROPOUT_RATE), 8, 700, 2)  # config, B, seed, steps
+
+
+def dropout_scale(rate):
+    """Dropout::scale as the reference computes it in float (src/layers/Dropout.cpp:15)."""
+    return np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+
+
+def pack_masks(masks):
+    return np.packbits(np.asarray(masks).reshape(-1) != 0)
+
+
+def unpack_masks(bits, shape, rate):
+    n = int(np.prod(shape))
+    keep = np.unpackbits(bits)[:n].astype(np.float32)
+    return (keep * dropout_scale(rate)).reshape(shape)
+
+
+def dropout_block_case():
+    D, H, h, B, N = 64, 160, 8, 3, 5
+    n = 4 * D + 4 * (D * D + D) + D * H + H + H * D + D
+    prm = rng_normal(30, n, scale=0.1)
+    prm[:D] += 1
+    prm[2 * D + 4 * (D * D + D):3 * D + 4 * (D * D + D)] += 1
+    return dict(D=D, H=H, h=h, B=B, N=N, n=n, rate=DROPOUT_RATE, prm=prm, x=rng_normal(31, B, N, D),
+                dy=rng_normal(32, B, N, D))
 
 
 def loss_curve_inputs():

@@ -46,6 +46,9 @@ SIGNATURES = {
     "vith_synchronize": (_int, []),
     "vith_seed": (_int, [_u64]),
     "vith_set_fused_attention": (_int, [_int]),
+    "vith_dropout_state": (_int, [_pu, _pu]),
+    "vith_set_dropout_state": (_int, [_u64, _u64]),
+    "vith_dropout_replay": (_int, [_p, _u64]),
     "vith_device_bytes_in_use": (_u64, []),
     "vith_model_create": (_p, [C.POINTER(Config), _int, _int]),
     "vith_model_destroy": (None, [_p]),
@@ -84,6 +87,7 @@ SIGNATURES = {
     "vith_cosine_warmup_lr": (_f, [_i64, _i64, _i64, _f]),
     "vith_epoch_order": (_int, [_u64, _i32, _p]),
     "vith_layer_create": (_p, [_int, _u64, _u64, _u64, _u64]),
+    "vith_layer_create_dropout": (_p, [_int, _u64, _u64, _u64, _u64, _f]),
     "vith_layer_destroy": (None, [_p]),
     "vith_layer_param_count": (_u64, [_p]),
     "vith_layer_set_params": (_int, [_p, _p]),
@@ -137,6 +141,39 @@ def set_fused_attention(on):
 
 def seed(s):
     _check(dll().vith_seed(s))
+
+
+def dropout_state():
+    """(seed, offset) the next training-mode Dropout forward will draw its mask from."""
+    s, o = C.c_uint64(), C.c_uint64()
+    _check(dll().vith_dropout_state(C.byref(s), C.byref(o)))
+    return s.value, o.value
+
+
+def set_dropout_state(seed_, offset):
+    _check(dll().vith_set_dropout_state(seed_, offset))
+
+
+def dropout_replay(masks):
+    """Dropout layers take their factors from `masks` (a CUDA tensor, call order) until dropout_replay(None)."""
+    if masks is None:
+        _check(dll().vith_dropout_replay(None, 0))
+    else:
+        _check(dll().vith_dropout_replay(masks.data_ptr(), masks.numel()))
+
+
+def dropout_masks(rate, seed_, offset, counts):
+    """The masks that consecutive Dropout forwards over counts[0], counts[1], ... elements draw from
+    stream position (seed_, offset): a list of CUDA tensors holding 0 or 1/(1-rate)."""
+    import torch
+    out = []
+    for n in counts:
+        ones = torch.ones(n, dtype=torch.float32, device="cuda")
+        y, m = torch.empty_like(ones), torch.empty_like(ones)
+        vitk.call("vitk_dropout_fwd", ones, n, rate, seed_, offset, y, m, vitk.stream())
+        out.append(m)
+        offset += (n + 3) // 4
+    return out
 
 
 def synchronize():
@@ -347,8 +384,8 @@ LAYER_KINDS = {"dense": 0, "layernorm": 1, "gelu": 2, "mha": 3, "ffn": 4, "block
 class Layer:
     """One reference Layer subclass (host-buffer in/out; for op-level parity tests)."""
 
-    def __init__(self, kind, a=0, b=0, c=0, d=0):
-        self.h = dll().vith_layer_create(LAYER_KINDS[kind], a, b, c, d)
+    def __init__(self, kind, a=0, b=0, c=0, d=0, dropout_rate=0.0):
+        self.h = dll().vith_layer_create_dropout(LAYER_KINDS[kind], a, b, c, d, dropout_rate)
         if not self.h:
             raise HostError(dll().vith_last_error().decode(errors="replace"))
         self.n = dll().vith_layer_param_count(self.h)

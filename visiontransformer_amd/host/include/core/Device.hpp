@@ -49,6 +49,14 @@ void dropout_stream(size_t count, uint64_t *seed_out, uint64_t *offset_out);
 // Position of the dropout stream (part of a resumable training state).
 void get_dropout_state(uint64_t *seed_out, uint64_t *offset_out);
 void set_dropout_state(uint64_t seed, uint64_t offset);
+// Replay of recorded dropout draws: while a buffer is set, every training-mode Dropout forward
+// takes its `count` factors (0 or 1/(1-rate)) from it, in call order, instead of the device
+// stream -- this repeats a run whose masks were recorded elsewhere (e.g. by the reference, whose
+// masks come from random_device).  nullptr / 0 ends the replay.  The buffer must stay alive until
+// the backward pass that uses it has run.
+void set_dropout_replay(const float *masks_dev, size_t count);
+// Next `count` recorded factors, or nullptr when no replay is active; throws when the buffer runs out.
+const float *dropout_replay_take(size_t count);
 
 }  // namespace vit
 

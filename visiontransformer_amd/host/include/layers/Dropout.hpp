@@ -25,6 +25,8 @@ private:
   // stream position and extent of the last training-mode forward (count 0: none)
   uint64_t seed = 0, offset = 0;
   size_t count = 0;
+  // recorded factors used by the last forward instead of the stream (vit::set_dropout_replay)
+  const float *replayed = nullptr;
 };
 
 #endif  // DROPOUT_HPP

@@ -23,6 +23,8 @@ struct State {
   std::mt19937_64 rng{std::random_device{}()};
   uint64_t dropout_seed = 0x5eedULL;
   uint64_t dropout_offset = 0;
+  const float *replay = nullptr;
+  size_t replay_left = 0;
 };
 
 State &S() {
@@ -181,6 +183,23 @@ void get_dropout_state(uint64_t *seed_out, uint64_t *offset_out) {
 void set_dropout_state(uint64_t seed, uint64_t offset) {
   S().dropout_seed = seed;
   S().dropout_offset = offset;
+}
+
+void set_dropout_replay(const float *masks_dev, size_t count) {
+  S().replay = count ? masks_dev : nullptr;
+  S().replay_left = masks_dev ? count : 0;
+}
+
+const float *dropout_replay_take(size_t count) {
+  State &s = S();
+  if (!s.replay) return nullptr;
+  if (count > s.replay_left)
+    throw std::runtime_error("dropout replay: the recorded masks are exhausted (" + std::to_string(count) +
+                             " factors wanted, " + std::to_string(s.replay_left) + " left)");
+  const float *p = s.replay;
+  s.replay += count;
+  s.replay_left -= count;
+  return p;
 }
 
 }  // namespace vit

@@ -199,6 +199,11 @@ Tensor Dropout::forward(const Tensor &input, bool isTraining) {
   if (!input.isContiguous()) throw std::runtime_error("Dropout::forward actualmente solo soporta tensores contiguos.");
   Tensor y = Tensor::deviceEmpty(input.getShape());
   count = input.getSize();
+  if ((replayed = vit::dropout_replay_take(count)) != nullptr) {
+    vit::check(vitk_dropout_bwd(input.deviceData(), replayed, (int64_t)count, y.deviceDataOverwrite(), S()),
+               "vitk_dropout_bwd");
+    return y;
+  }
   vit::dropout_stream(count, &seed, &offset);
   vit::check(vitk_dropout_residual_fwd(input.deviceData(), nullptr, (int64_t)count, rate, seed, offset,
                                        y.deviceDataOverwrite(), nullptr, S()),
@@ -215,6 +220,13 @@ Tensor Dropout::forwardAdd(const Tensor &input, const Tensor &residual, bool isT
     throw std::runtime_error("Dropout::forwardAdd espera dos tensores contiguos del mismo tamano.");
   Tensor y = Tensor::deviceEmpty(input.getShape());
   count = input.getSize();
+  if ((replayed = vit::dropout_replay_take(count)) != nullptr) {
+    vit::check(vitk_dropout_bwd(input.deviceData(), replayed, (int64_t)count, y.deviceDataOverwrite(), S()),
+               "vitk_dropout_bwd");
+    vit::check(vitk_add_f32(residual.deviceData(), y.deviceData(), (int64_t)count, y.deviceDataOverwrite(), S()),
+               "vitk_add_f32");
+    return y;
+  }
   vit::dropout_stream(count, &seed, &offset);
   vit::check(vitk_dropout_residual_fwd(input.deviceData(), residual.deviceData(), (int64_t)count, rate, seed, offset,
                                        y.deviceDataOverwrite(), nullptr, S()),
@@ -227,6 +239,11 @@ Tensor Dropout::backward(const Tensor &outputGradient) {
   if (!outputGradient.isContiguous() || outputGradient.getSize() != count)
     throw std::runtime_error("Dropout::backward espera un gradiente contiguo con la forma de la entrada.");
   Tensor dx = Tensor::deviceEmpty(outputGradient.getShape());
+  if (replayed) {
+    vit::check(vitk_dropout_bwd(outputGradient.deviceData(), replayed, (int64_t)count, dx.deviceDataOverwrite(), S()),
+               "vitk_dropout_bwd");
+    return dx;
+  }
   vit::check(vitk_dropout_stream_bwd(outputGradient.deviceData(), (int64_t)count, rate, seed, offset,
                                      dx.deviceDataOverwrite(), S()),
              "vitk_dropout_stream_bwd");

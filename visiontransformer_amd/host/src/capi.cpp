@@ -94,6 +94,18 @@ int vith_seed(uint64_t seed) { return guard([&] { vit::seed(seed); }); }
 int vith_set_fused_attention(int on) {
   return guard([&] { MultiHeadAttention::setDefaultFused(on != 0); });
 }
+int vith_dropout_state(uint64_t *seed, uint64_t *offset) {
+  return guard([&] {
+    if (!seed || !offset) throw std::invalid_argument("vith_dropout_state: null pointer");
+    vit::get_dropout_state(seed, offset);
+  });
+}
+int vith_set_dropout_state(uint64_t seed, uint64_t offset) {
+  return guard([&] { vit::set_dropout_state(seed, offset); });
+}
+int vith_dropout_replay(const float *masks_dev, uint64_t count) {
+  return guard([&] { vit::set_dropout_replay(masks_dev, (size_t)count); });
+}
 uint64_t vith_device_bytes_in_use(void) { return vit::device_bytes_in_use(); }
 
 vith_model vith_model_create(const vith_config *cfg, int patch_mode, int dk_mode) {
@@ -383,6 +395,9 @@ int vith_epoch_order(uint64_t n, int32_t epoch, uint64_t *out) {
 }
 
 vith_layer vith_layer_create(int kind, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+  return vith_layer_create_dropout(kind, a, b, c, d, 0.0f);
+}
+vith_layer vith_layer_create_dropout(int kind, uint64_t a, uint64_t b, uint64_t c, uint64_t d, float dropout_rate) {
   LayerBox *box = nullptr;
   const int rc = guard([&] {
     std::unique_ptr<Layer> l;
@@ -391,8 +406,8 @@ vith_layer vith_layer_create(int kind, uint64_t a, uint64_t b, uint64_t c, uint6
       case 1: l = std::make_unique<LayerNorm>(a); break;
       case 2: l = std::make_unique<GELU>(); break;
       case 3: l = std::make_unique<MultiHeadAttention>(a, b); break;
-      case 4: l = std::make_unique<FeedForward>(a, b, 0.0f); break;
-      case 5: l = std::make_unique<TransformerEncoderBlock>(a, b, c, 0.0f); break;
+      case 4: l = std::make_unique<FeedForward>(a, b, dropout_rate); break;
+      case 5: l = std::make_unique<TransformerEncoderBlock>(a, b, c, dropout_rate); break;
       case 6: l = std::make_unique<Embeddings>(a, a, b, c, d); break;
       default: throw std::invalid_argument("vith_layer_create: unknown kind");
     }
