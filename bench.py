@@ -144,8 +144,9 @@ def main():
     host.seed(42)  # identical N(0, 0.02) init on every rank (then broadcast from rank 0 anyway)
     model = host.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
     trainer = host.Trainer(model, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4)
-    engine = dp.HostEngine(model, trainer)
-    ddp = dp.DataParallel(engine, bucket_bytes=int(args.bucket_mb * (1 << 20)), always_reduce=args.force_collectives)
+    if world > 1 or args.force_collectives:
+        dp.init_rccl()  # the host layer's own RCCL communicator; torch's group only carries the id
+    ddp = dp.NativeDataParallel(model, trainer, bucket_bytes=int(args.bucket_mb * (1 << 20)))
     ddp.broadcast_parameters(0)
 
     # synthetic batch, resident in HBM: images N(0,1) (the scale of normalised MNIST), uniform labels
@@ -197,10 +198,13 @@ def main():
             "config": {"workload": f"{args.workload}: ViT {cfgd['image_size']}x{cfgd['image_size']}x{cfgd['in_channels']}"
                                    f" patch {cfgd['patch_size']} d={cfgd['embedding_dim']} L={cfgd['num_layers']}"
                                    f" h={cfgd['num_heads']} mlp={cfgd['mlp_hidden_dim']} K={cfgd['num_classes']}"
-                                   " (K=1000 assumed: BASELINE.json does not give the class count), one training"
+                                   + (" (K=1000 assumed: BASELINE.json does not give the class count)"
+                                      if cfgd["num_classes"] == 1000 else "") + ", one training"
                                    " step = fwd + softmax-CE + bwd + Adam(L2), dropout " + (f"{args.dropout:g}") + ", random-init weights",
                        "batch_per_gpu": batch, "global_batch": batch * world,
-                       "parallelism": f"dp{world}" + (" (bucketed RCCL all-reduce overlapped with backward)" if world > 1 else ""),
+                       "parallelism": f"dp{world}" + (f" ({trainer.num_buckets()} gradient buckets, ncclAllReduce on a side"
+                                                      " HIP stream overlapped with backward)"
+                                                      if (world > 1 or args.force_collectives) else ""),
                        "patch_mode": "im2col", "params": int(model.n), "final_loss": round(float(loss), 6)},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -221,6 +225,7 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
+        host.comm_destroy()
         dist.destroy_process_group()
 
 

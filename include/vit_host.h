@@ -35,6 +35,43 @@ int vith_set_stream(void *hip_stream);
 int vith_synchronize(void);
 /* seeds weight initialisation, data subsampling and dropout (the reference uses random_device) */
 int vith_seed(uint64_t seed);
+/* ---- data parallelism: one process per GPU, gradients all-reduced with RCCL over xGMI -----------
+ * The reference has none (single process, single device); this is the exchange step around its
+ * per-batch body (Trainer::train_epoch, src/model/Trainer.cpp:163-236).  While a communicator
+ * exists:
+ *   - vith_step_backward_stage(s) also enqueues, on a library-owned side stream gated by events,
+ *     one ncclAllReduce(float, sum) for every gradient bucket that stage s closes (consecutive
+ *     stage slices of the gradient arena merged until they hold >= bucket_bytes, default 25 MiB),
+ *     so the exchange overlaps the remaining backward kernels;
+ *   - vith_step_update first makes the compute stream wait for all buckets, then runs Adam;
+ *   - vith_step_forward's grad_batch must be the GLOBAL batch, so that the sum is the single-device
+ *     gradient; vith_fit shards every global batch of world x batch_size samples by rank;
+ *   - every rank draws its own dropout masks.
+ * vith_comm_unique_id: rank 0 creates the 128-byte id and passes it to the other ranks by any
+ * channel; vith_comm_init (collective) joins.  vith_comm_init_file exchanges the id through a file
+ * instead (rank 0 writes it, the others wait up to timeout_s seconds; 0 = 120).  A C++ application
+ * needs none of these calls: Trainer joins by itself when the launcher has set WORLD_SIZE > 1
+ * (RANK, LOCAL_RANK, optional VIT_COMM_ID_FILE).
+ * vith_comm_init_external: the transport is the caller's (a test harness, another framework's
+ * process group).  Both functions work in place on device memory; a stream-ordered transport
+ * (stream_ordered = 1) enqueues on `stream` and returns, a host-synchronous one (0) must wait for
+ * `stream` before reading and have the result in place when it returns. */
+typedef int (*vith_allreduce_fn)(float *dev, uint64_t count, void *stream, void *user);
+typedef int (*vith_broadcast_fn)(float *dev, uint64_t count, int root, void *stream, void *user);
+int vith_comm_unique_id(void *id128);
+int vith_comm_init(int rank, int world, const void *id128);
+int vith_comm_init_file(int rank, int world, const char *path, int timeout_s);
+int vith_comm_init_external(int rank, int world, vith_allreduce_fn allreduce, vith_broadcast_fn broadcast, void *user,
+                            int stream_ordered);
+int vith_comm_destroy(void);
+/* The bucket rule on its own (pure host code): stage s finalises [stage_offset[s], +stage_count[s])
+ * of the gradient arena, slices adjacent and descending; out3 receives {last stage, offset, count}
+ * per bucket.  Returns the number of buckets, -1 on error. */
+int64_t vith_plan_buckets(const uint64_t *stage_offset, const uint64_t *stage_count, uint64_t stages,
+                          uint64_t bucket_bytes, uint64_t *out3, uint64_t out_capacity);
+int vith_comm_rank(void);
+int vith_comm_world(void);
+
 /* Dropout draws (src/layers/Dropout.cpp:42-51).  The reference seeds each mask from random_device;
  * here the factors of a Dropout forward over n elements are a pure function of (seed, offset,
  * element index) -- the mask vitk_dropout_fwd produces for the same (rate, seed, offset) -- and the
@@ -138,6 +175,13 @@ uint64_t vith_num_stages(vith_trainer t);
 int vith_step_backward_stage(vith_trainer t, uint64_t stage);
 int vith_stage_grad_range(vith_trainer t, uint64_t stage, uint64_t *offset, uint64_t *count);
 int vith_step_update(vith_trainer t, float lr, float grad_scale);
+/* data parallelism: replicas start from rank `root`'s parameters; sum of `count` device floats over
+ * the ranks on the compute stream (metrics); bucket size of this trainer's gradient exchange and
+ * the number of buckets it gives (0 without a communicator) */
+int vith_comm_broadcast_params(vith_model m, int root);
+int vith_comm_allreduce(float *dev, uint64_t count);
+int vith_trainer_set_bucket_bytes(vith_trainer t, uint64_t bytes);
+uint64_t vith_trainer_num_buckets(vith_trainer t);
 /* Resumable optimizer state: Adam's step count and both moment buffers plus the position of the
  * dropout stream, written to / read from one file.  With vith_save_weights it continues a
  * run bit for bit (the reference keeps this state in memory only and cannot resume). */

@@ -92,3 +92,18 @@ def test_config_json_round_trip_matches_reference_file(tmp_path):
     assert back.as_dict() == cfg2.as_dict()
     with pytest.raises(host.HostError):
         host.load_config(str(tmp_path / "missing.json"))
+
+
+def test_bucket_plan_of_the_host_layer_matches_the_python_driver():
+    """The gradient-bucket rule exists twice (vit::GradientReducer in C++, dp.plan_buckets for the
+    generic Python driver): same plan for ViT-B-like stage sizes at several bucket sizes."""
+    from visiontransformer_amd import dp, host
+    emb, blk, tail, L = 742_656, 7_087_872, 770_536, 12
+    offs = [0, emb] + [emb + blk * (i + 1) for i in range(L)] + [emb + blk * L + tail]
+    ranges = [(offs[-2], tail)] + [(offs[i], blk) for i in range(L, 0, -1)] + [(0, emb)]
+    for bb in (1, 1 << 20, 25 << 20, 50 << 20, 1 << 40):
+        want = dp.plan_buckets(ranges, bb)
+        assert host.plan_buckets(ranges, bb) == [tuple(b) for b in want], bb
+    assert len(host.plan_buckets(ranges, 25 << 20)) == 13  # head+last block, 11 blocks, embeddings
+    with pytest.raises(host.HostError):
+        host.plan_buckets([(0, 4), (100, 4)], 1 << 20)  # slices of one bucket must be adjacent

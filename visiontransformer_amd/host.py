@@ -46,6 +46,18 @@ SIGNATURES = {
     "vith_synchronize": (_int, []),
     "vith_seed": (_int, [_u64]),
     "vith_set_fused_attention": (_int, [_int]),
+    "vith_comm_unique_id": (_int, [_p]),
+    "vith_comm_init": (_int, [_int, _int, _p]),
+    "vith_comm_init_file": (_int, [_int, _int, C.c_char_p, _int]),
+    "vith_comm_init_external": (_int, [_int, _int, _p, _p, _p, _int]),
+    "vith_comm_destroy": (_int, []),
+    "vith_plan_buckets": (_i64, [_pu, _pu, _u64, _u64, _pu, _u64]),
+    "vith_comm_rank": (_int, []),
+    "vith_comm_world": (_int, []),
+    "vith_comm_broadcast_params": (_int, [_p, _int]),
+    "vith_comm_allreduce": (_int, [_p, _u64]),
+    "vith_trainer_set_bucket_bytes": (_int, [_p, _u64]),
+    "vith_trainer_num_buckets": (_u64, [_p]),
     "vith_dropout_state": (_int, [_pu, _pu]),
     "vith_set_dropout_state": (_int, [_u64, _u64]),
     "vith_dropout_replay": (_int, [_p, _u64]),
@@ -141,6 +153,88 @@ def set_fused_attention(on):
 
 def seed(s):
     _check(dll().vith_seed(s))
+
+
+# ---- data parallelism (include/vit_host.h: vith_comm_*) ----------------------------------------
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p)
+BROADCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p)
+_transport_keepalive = []
+
+
+def comm_unique_id():
+    """The 128-byte id rank 0 creates for a new RCCL communicator."""
+    buf = C.create_string_buffer(128)
+    _check(dll().vith_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(rank, world, unique_id):
+    """Join the RCCL communicator (collective over all ranks)."""
+    assert len(unique_id) == 128
+    _check(dll().vith_comm_init(rank, world, unique_id))
+
+
+def comm_init_file(rank, world, path, timeout_s=120):
+    _check(dll().vith_comm_init_file(rank, world, os.fsencode(path), timeout_s))
+
+
+def comm_init_external(rank, world, allreduce, broadcast, stream_ordered):
+    """allreduce(dev_ptr, count, stream) / broadcast(dev_ptr, count, root, stream): Python callables
+    working in place on device memory; exceptions they raise become a transport failure."""
+    errors = []
+
+    def ar(dev, count, stream, _user):
+        try:
+            allreduce(dev, count, stream)
+            return 0
+        except Exception as e:  # noqa: BLE001 - must not unwind through the C++ caller
+            errors.append(e)
+            return 1
+
+    def bc(dev, count, root, stream, _user):
+        try:
+            broadcast(dev, count, root, stream)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            return 1
+
+    fns = (ALLREDUCE_FN(ar), BROADCAST_FN(bc), errors)
+    _transport_keepalive.append(fns)
+    _check(dll().vith_comm_init_external(rank, world, C.cast(fns[0], C.c_void_p), C.cast(fns[1], C.c_void_p), None,
+                                         int(stream_ordered)))
+    return errors
+
+
+def plan_buckets(ranges, bucket_bytes):
+    """vit::GradientReducer::planBuckets: [(last_stage, offset, count), ...] for stage slices
+    ranges[s] = (offset, count)."""
+    n = len(ranges)
+    off = (C.c_uint64 * n)(*[r[0] for r in ranges])
+    cnt = (C.c_uint64 * n)(*[r[1] for r in ranges])
+    out = (C.c_uint64 * (3 * max(n, 1)))()
+    k = dll().vith_plan_buckets(off, cnt, n, bucket_bytes, out, max(n, 1))
+    if k < 0:
+        raise HostError(dll().vith_last_error().decode(errors="replace"))
+    return [(int(out[3 * i]), int(out[3 * i + 1]), int(out[3 * i + 2])) for i in range(k)]
+
+
+def comm_destroy():
+    _check(dll().vith_comm_destroy())
+    _transport_keepalive.clear()
+
+
+def comm_rank():
+    return dll().vith_comm_rank()
+
+
+def comm_world():
+    return dll().vith_comm_world()
+
+
+def comm_allreduce(t):
+    """In-place sum of a float32 CUDA tensor over the ranks, on the compute stream."""
+    _check(dll().vith_comm_allreduce(t.data_ptr(), t.numel()))
 
 
 def dropout_state():
@@ -262,6 +356,10 @@ class Model:
         _check(dll().vith_get_grads(self.h, out.ctypes.data))
         return out
 
+    def broadcast_params(self, root=0):
+        """Data parallelism: every replica takes rank `root`'s parameters."""
+        _check(dll().vith_comm_broadcast_params(self.h, root))
+
     def params_device(self):
         return dll().vith_params_device(self.h)
 
@@ -352,6 +450,12 @@ class Trainer:
 
     def backward_stage(self, s):
         _check(dll().vith_step_backward_stage(self.h, s))
+
+    def set_bucket_bytes(self, n):
+        _check(dll().vith_trainer_set_bucket_bytes(self.h, int(n)))
+
+    def num_buckets(self):
+        return dll().vith_trainer_num_buckets(self.h)
 
     def save_state(self, path):
         _check(dll().vith_trainer_save_state(self.h, os.fsencode(path)))

@@ -49,6 +49,10 @@ void dropout_stream(size_t count, uint64_t *seed_out, uint64_t *offset_out);
 // Position of the dropout stream (part of a resumable training state).
 void get_dropout_state(uint64_t *seed_out, uint64_t *offset_out);
 void set_dropout_state(uint64_t seed, uint64_t offset);
+// Data parallelism: rank r draws from the stream keyed by seed + r * (an odd constant), so that the
+// ranks apply different masks to their different samples.  The seed reported by
+// get_dropout_state and passed to the kernels is that effective key.
+void set_dropout_rank(int rank);
 // Replay of recorded dropout draws: while a buffer is set, every training-mode Dropout forward
 // takes its `count` factors (0 or 1/(1-rate)) from it, in call order, instead of the device
 // stream -- this repeats a run whose masks were recorded elsewhere (e.g. by the reference, whose

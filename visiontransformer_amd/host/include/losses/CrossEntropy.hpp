@@ -25,6 +25,7 @@ public:
   // enqueue only (no host sync): results land in resultBuffer() = {loss, correct}
   void enqueue(const Tensor &yPred, const Tensor &yTrue);
   const Tensor &resultBuffer() const { return out2; }
+  const float *resultDevice() const { return out2.deviceData(); }
 
 private:
   Tensor softmaxOutput, gradient, out2, scratch, weightsDevice;

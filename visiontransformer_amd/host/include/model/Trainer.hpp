@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "core/Comm.hpp"
 #include "losses/CrossEntropy.hpp"
 #include "model/VisionTransformer.hpp"
 #include "optimizers/Adam.hpp"
@@ -40,6 +41,13 @@ struct TrainerConfig {
   bool augment = false;
   uint32_t augment_seed = 0;
   DataAugmentation::Config augment_config;
+  // Data parallelism (one process per GPU).  When a communicator exists (vit::comm_init_*; the
+  // Trainer also joins one by itself when the launcher has set WORLD_SIZE > 1, see
+  // vit::comm_init_from_env) batch_size is the batch PER RANK: every step consumes
+  // world x batch_size samples of the epoch's shuffled order, rank r taking the r-th slice, and
+  // gradients are all-reduced in buckets of at least bucket_bytes while backward runs.  All ranks
+  // start from rank 0's parameters; rank 0 alone logs and writes files.
+  size_t bucket_bytes = 25u << 20;
 };
 
 class Trainer {
@@ -71,6 +79,10 @@ public:
 
 private:
   std::pair<float, float> train_epoch(const Tensor &X_train, const Tensor &y_train, int epoch);
+  // the data-parallel form of trainStep: local batch may be empty (X_batch undefined) on the ragged
+  // last step; global_count = samples of this step over all ranks
+  float trainStepParallel(const Tensor &X_batch, const Tensor &y_batch, size_t local_count, size_t global_count,
+                          float lr_now, float *accuracy);
 
   VisionTransformer &model;
   Adam optimizer;
@@ -82,6 +94,8 @@ private:
   float best_test_acc = 0.0f;
   std::vector<std::array<float, 4>> epoch_history;
   bool quiet = false;
+  std::unique_ptr<vit::GradientReducer> reducer;  // set when a communicator exists
+  Tensor metrics;                                 // {loss sum, correct} exchanged per step
 };
 
 #endif  // TRAINER_HPP

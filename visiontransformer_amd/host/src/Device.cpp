@@ -23,6 +23,7 @@ struct State {
   std::mt19937_64 rng{std::random_device{}()};
   uint64_t dropout_seed = 0x5eedULL;
   uint64_t dropout_offset = 0;
+  uint64_t dropout_salt = 0;
   const float *replay = nullptr;
   size_t replay_left = 0;
 };
@@ -170,20 +171,22 @@ uint64_t next_seed() { return S().rng(); }
 
 void dropout_stream(size_t count, uint64_t *seed_out, uint64_t *offset_out) {
   State &s = S();
-  *seed_out = s.dropout_seed;
+  *seed_out = s.dropout_seed + s.dropout_salt;
   *offset_out = s.dropout_offset;
   s.dropout_offset += (count + 3) / 4;
 }
 
 void get_dropout_state(uint64_t *seed_out, uint64_t *offset_out) {
-  *seed_out = S().dropout_seed;
+  *seed_out = S().dropout_seed + S().dropout_salt;
   *offset_out = S().dropout_offset;
 }
 
 void set_dropout_state(uint64_t seed, uint64_t offset) {
-  S().dropout_seed = seed;
+  S().dropout_seed = seed - S().dropout_salt;
   S().dropout_offset = offset;
 }
+
+void set_dropout_rank(int rank) { S().dropout_salt = 0xD1B54A32D192ED03ULL * (uint64_t)rank; }
 
 void set_dropout_replay(const float *masks_dev, size_t count) {
   S().replay = count ? masks_dev : nullptr;

@@ -16,15 +16,35 @@
 #include "optimizers/Scheduler.hpp"
 #include "utils/ModelUtils.hpp"
 
+namespace {
+// Joins the launcher's communicator if there is one (WORLD_SIZE > 1) before anything is opened:
+// only rank 0 writes the epoch log.
+const char *log_path() {
+  vit::comm_init_from_env();
+  return vit::comm_rank() == 0 ? "vit_results.csv" : "/dev/null";
+}
+}  // namespace
+
 Trainer::Trainer(VisionTransformer &model, const TrainerConfig &train_config, const std::vector<float> &class_weights)
     : model(model), optimizer(train_config.learning_rate, 0.9f, 0.999f, 1e-8f, train_config.weight_decay), loss_fn(),
-      config(train_config), logger("vit_results.csv") {
+      config(train_config), logger(log_path()) {
   loss_fn.setClassWeights(class_weights);
+  if (vit::comm_active()) {
+    reducer = std::make_unique<vit::GradientReducer>(model, config.bucket_bytes);
+    // replicas start from rank 0's parameters (each process initialised its own)
+    auto &p = model.arena().params();
+    vit::comm_broadcast(p->dev_write(), p->count, 0);
+    if (vit::comm_rank() != 0) quiet = true;
+  }
 }
 
 // forward(train) -> loss/accuracy -> loss gradient -> model backward -> LR -> Adam
 // (src/model/Trainer.cpp:201-227).  Top-1 hits come out of the fused loss kernel.
 float Trainer::trainStep(const Tensor &X_batch, const Tensor &y_batch, float lr_now, float *accuracy) {
+  if (reducer) {
+    const size_t local = X_batch.getShape()[0];
+    return trainStepParallel(X_batch, y_batch, local, local * (size_t)vit::comm_world(), lr_now, accuracy);
+  }
   Tensor logits = model.forward(X_batch, true);
   const float batch_loss = loss_fn.calculate(logits, y_batch);
   if (accuracy) *accuracy = loss_fn.lastCorrect() / static_cast<float>(X_batch.getShape()[0]);
@@ -37,10 +57,52 @@ float Trainer::trainStep(const Tensor &X_batch, const Tensor &y_batch, float lr_
   return batch_loss;
 }
 
+// The same step with the batch sharded over the ranks of the communicator: the loss gradient is
+// divided by the GLOBAL batch, backward runs stage by stage and each closed gradient bucket is
+// all-reduced (sum) on the side stream meanwhile; Adam follows once every bucket has landed.
+// Returns the loss of the global batch (the ranks' loss sums are exchanged with the hit counts).
+float Trainer::trainStepParallel(const Tensor &X_batch, const Tensor &y_batch, size_t local_count, size_t global_count,
+                                 float lr_now, float *accuracy) {
+  void *st = vit::stream();
+  if (!metrics.defined()) metrics = Tensor::deviceEmpty({2});
+  float *mdev = metrics.deviceDataOverwrite();
+  if (local_count > 0) {
+    Tensor logits = model.forward(X_batch, true);
+    loss_fn.setGradientBatch((float)global_count);
+    loss_fn.enqueue(logits, y_batch);
+    const float *r = loss_fn.resultDevice();  // {mean loss of the local batch, hits}
+    vit::check(vitk_scale_f32(r, (float)local_count, 1, mdev, st), "vitk_scale_f32");
+    vit::check(vitk_scale_f32(r + 1, 1.0f, 1, mdev + 1, st), "vitk_scale_f32");
+    model.backwardBegin(loss_fn.backward(logits, y_batch));
+    for (size_t s = 0; s < model.numBackwardStages(); ++s) {
+      model.backwardStage(s);
+      reducer->afterStage(s);
+    }
+  } else {
+    // nothing of the (ragged) last global batch fell to this rank: it contributes zeros
+    auto &g = model.arena().grads();
+    vit::zero_device(g->dev_overwrite(), g->count);
+    vit::zero_device(mdev, 2);
+    for (size_t s = 0; s < model.numBackwardStages(); ++s) reducer->afterStage(s);
+  }
+  reducer->finish();
+  vit::comm_allreduce(mdev, 2);
+  auto params = model.getParameters();
+  auto grads = model.getGradients();
+  optimizer.setLearningRate(lr_now);
+  optimizer.update(params, grads);
+  float sums[2];
+  vit::copy_to_host(sums, mdev, 2);  // synchronises, like the reference's per-batch loss read
+  if (accuracy) *accuracy = sums[1] / static_cast<float>(global_count);
+  return sums[0] / static_cast<float>(global_count);
+}
+
 void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair<Tensor, Tensor> &test_data) {
   const Tensor &X_train = train_data.first, &y_train = train_data.second;
   const Tensor &X_test = test_data.first, &y_test = test_data.second;
-  const size_t batches_per_epoch = (X_train.getShape()[0] + config.batch_size - 1) / config.batch_size;
+  const size_t global_batch = config.batch_size * (size_t)vit::comm_world();
+  const size_t batches_per_epoch = (X_train.getShape()[0] + global_batch - 1) / global_batch;
+  const bool root = vit::comm_rank() == 0;
   total_steps = (long long)batches_per_epoch * config.epochs;
   for (int epoch = config.start_epoch; epoch < config.epochs; ++epoch) {
     const auto start = std::chrono::high_resolution_clock::now();
@@ -52,10 +114,10 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
     logger.log_epoch(epoch, config.epochs, train_loss, train_acc, test_loss, test_acc);
     epoch_history.push_back({train_loss, train_acc, test_loss, test_acc});
     if (!config.best_weights_path.empty() && test_acc > best_test_acc && test_acc > train_acc) {
-      ModelUtils::save_weights(model, config.best_weights_path);
+      if (root) ModelUtils::save_weights(model, config.best_weights_path);
       best_test_acc = test_acc;
     }
-    if (!config.state_path.empty()) {
+    if (!config.state_path.empty() && root) {
       ModelUtils::save_weights(model, config.state_path + ".weights");
       saveState(config.state_path, epoch + 1);
     }
@@ -115,7 +177,9 @@ int Trainer::loadState(const std::string &path) {
 std::pair<float, float> Trainer::train_epoch(const Tensor &X_train, const Tensor &y_train, int epoch) {
   const auto &shape = X_train.getShape();
   const size_t n = shape[0], sample = shape[1] * shape[2] * shape[3], K = y_train.getShape()[1];
-  const size_t num_batches = (n + config.batch_size - 1) / config.batch_size;
+  const size_t world = (size_t)vit::comm_world(), rank = (size_t)vit::comm_rank();
+  const size_t global_batch = config.batch_size * world;
+  const size_t num_batches = (n + global_batch - 1) / global_batch;
   float total_loss = 0.0f, total_accuracy = 0.0f;
   // sample order of the epoch: iota shuffled by mt19937(epoch) (src/model/Trainer.cpp:151-154)
   std::vector<size_t> indices(n);
@@ -146,12 +210,20 @@ std::pair<float, float> Trainer::train_epoch(const Tensor &X_train, const Tensor
     aug = reinterpret_cast<const vitk_augment_params *>(aug_dev.deviceData());
   }
   for (size_t i = 0; i < num_batches; ++i) {
-    const size_t first = i * config.batch_size;
-    const size_t count = std::min(config.batch_size, n - first);
-    if (count == 0) continue;
-    Tensor X_batch = Tensor::deviceEmpty({count, shape[1], shape[2], shape[3]});
-    Tensor y_batch = Tensor::deviceEmpty({count, K});
-    if (aug != nullptr)
+    // this step's slice of the shuffled order: [i*global_batch, ...) holds global_count samples,
+    // of which this rank takes the rank-th run of batch_size (short or empty at the ragged end)
+    const size_t global_count = std::min(global_batch, n - i * global_batch);
+    const size_t lo = std::min(rank * config.batch_size, global_count);
+    const size_t count = std::min(config.batch_size, global_count - lo);
+    const size_t first = i * global_batch + lo;
+    if (count == 0 && !reducer) continue;
+    Tensor X_batch, y_batch;
+    if (count > 0) {
+      X_batch = Tensor::deviceEmpty({count, shape[1], shape[2], shape[3]});
+      y_batch = Tensor::deviceEmpty({count, K});
+    }
+    if (count == 0) {
+    } else if (aug != nullptr)
       vit::check(vitk_augment_f32(xsrc, (int64_t)n, order + first, aug + first, (int64_t)count, (int32_t)shape[1],
                                   (int32_t)shape[2], (int32_t)shape[3], X_batch.deviceDataOverwrite(), vit::stream()),
                  "vitk_augment_f32");
@@ -159,13 +231,15 @@ std::pair<float, float> Trainer::train_epoch(const Tensor &X_train, const Tensor
       vit::check(vitk_gather_rows_f32(xsrc, (int64_t)n, order + first, (int64_t)count, (int64_t)sample,
                                       X_batch.deviceDataOverwrite(), vit::stream()),
                  "vitk_gather_rows_f32");
-    vit::check(vitk_gather_rows_f32(ysrc, (int64_t)n, order + first, (int64_t)count, (int64_t)K,
-                                    y_batch.deviceDataOverwrite(), vit::stream()),
-               "vitk_gather_rows_f32");
+    if (count > 0)
+      vit::check(vitk_gather_rows_f32(ysrc, (int64_t)n, order + first, (int64_t)count, (int64_t)K,
+                                      y_batch.deviceDataOverwrite(), vit::stream()),
+                 "vitk_gather_rows_f32");
     const long long warmup_steps = (long long)(config.warmup_frac * total_steps);
     const float lr_now = cosine_warmup_lr(global_step, warmup_steps, total_steps, config.lr_init);
     float acc = 0.0f;
-    const float batch_loss = trainStep(X_batch, y_batch, lr_now, &acc);
+    const float batch_loss = reducer ? trainStepParallel(X_batch, y_batch, count, global_count, lr_now, &acc)
+                                     : trainStep(X_batch, y_batch, lr_now, &acc);
     total_loss += batch_loss;
     total_accuracy += acc;
     global_step++;

@@ -8,6 +8,7 @@
 #include <random>
 #include <string>
 
+#include "core/Comm.hpp"
 #include "core/Device.hpp"
 #include "core/Ops.hpp"
 #include "model/Trainer.hpp"
@@ -60,7 +61,18 @@ struct TrainerState {
   CrossEntropy loss;
   Adam adam;
   Tensor logits, labels;
+  // gradient exchange of the staged step; created on the first step that finds a communicator
+  std::unique_ptr<vit::GradientReducer> reducer;
+  size_t bucket_bytes = 25u << 20;
   TrainerState(Model *m, float b1, float b2, float eps, float wd) : model(m), adam(0.0f, b1, b2, eps, wd) {}
+  vit::GradientReducer *exchange() {
+    if (!vit::comm_active()) {
+      reducer.reset();
+      return nullptr;
+    }
+    if (!reducer) reducer = std::make_unique<vit::GradientReducer>(model->vit, bucket_bytes);
+    return reducer.get();
+  }
 };
 
 struct LayerBox {
@@ -93,6 +105,67 @@ int vith_synchronize(void) { return guard([&] { vit::synchronize(); }); }
 int vith_seed(uint64_t seed) { return guard([&] { vit::seed(seed); }); }
 int vith_set_fused_attention(int on) {
   return guard([&] { MultiHeadAttention::setDefaultFused(on != 0); });
+}
+int vith_comm_unique_id(void *id128) {
+  return guard([&] {
+    if (!id128) throw std::invalid_argument("vith_comm_unique_id: null pointer");
+    vit::comm_unique_id(id128);
+  });
+}
+int vith_comm_init(int rank, int world, const void *id128) {
+  return guard([&] { vit::comm_init_rccl(rank, world, id128); });
+}
+int vith_comm_init_file(int rank, int world, const char *path, int timeout_s) {
+  return guard([&] {
+    if (!path) throw std::invalid_argument("vith_comm_init_file: null path");
+    vit::comm_init_rccl_file(rank, world, path, timeout_s > 0 ? timeout_s : 120);
+  });
+}
+int vith_comm_init_external(int rank, int world, vith_allreduce_fn allreduce, vith_broadcast_fn broadcast, void *user,
+                            int stream_ordered) {
+  return guard([&] { vit::comm_init_external(rank, world, allreduce, broadcast, user, stream_ordered != 0); });
+}
+int vith_comm_destroy(void) { return guard([&] { vit::comm_destroy(); }); }
+int vith_comm_rank(void) { return vit::comm_rank(); }
+int vith_comm_world(void) { return vit::comm_world(); }
+int vith_comm_broadcast_params(vith_model m, int root) {
+  return guard([&] {
+    auto &p = M(m)->vit.arena().params();
+    vit::comm_broadcast(p->dev_write(), p->count, root);
+  });
+}
+int vith_comm_allreduce(float *dev, uint64_t count) {
+  return guard([&] { vit::comm_allreduce(dev, (size_t)count); });
+}
+int vith_trainer_set_bucket_bytes(vith_trainer t, uint64_t bytes) {
+  return guard([&] {
+    T(t)->bucket_bytes = (size_t)bytes;
+    T(t)->reducer.reset();
+  });
+}
+uint64_t vith_trainer_num_buckets(vith_trainer t) {
+  uint64_t n = 0;
+  guard([&] {
+    if (auto *r = T(t)->exchange()) n = r->buckets().size();
+  });
+  return n;
+}
+int64_t vith_plan_buckets(const uint64_t *stage_offset, const uint64_t *stage_count, uint64_t stages,
+                          uint64_t bucket_bytes, uint64_t *out3, uint64_t out_capacity) {
+  int64_t n = -1;
+  guard([&] {
+    std::vector<std::pair<size_t, size_t>> r(stages);
+    for (uint64_t i = 0; i < stages; ++i) r[i] = {(size_t)stage_offset[i], (size_t)stage_count[i]};
+    auto plan = vit::GradientReducer::planBuckets(r, (size_t)bucket_bytes);
+    if (plan.size() > out_capacity) throw std::runtime_error("vith_plan_buckets: output too small");
+    for (size_t i = 0; i < plan.size(); ++i) {
+      out3[3 * i] = plan[i].last_stage;
+      out3[3 * i + 1] = plan[i].offset;
+      out3[3 * i + 2] = plan[i].count;
+    }
+    n = (int64_t)plan.size();
+  });
+  return n;
 }
 int vith_dropout_state(uint64_t *seed, uint64_t *offset) {
   return guard([&] {
@@ -241,7 +314,10 @@ int vith_step_forward(vith_trainer t, const float *x_dev, const float *y_dev, ui
 }
 uint64_t vith_num_stages(vith_trainer t) { return T(t)->model->vit.numBackwardStages(); }
 int vith_step_backward_stage(vith_trainer t, uint64_t stage) {
-  return guard([&] { T(t)->model->vit.backwardStage((size_t)stage); });
+  return guard([&] {
+    T(t)->model->vit.backwardStage((size_t)stage);
+    if (auto *r = T(t)->exchange()) r->afterStage((size_t)stage);
+  });
 }
 int vith_stage_grad_range(vith_trainer t, uint64_t stage, uint64_t *offset, uint64_t *count) {
   return guard([&] {
@@ -254,6 +330,7 @@ int vith_stage_grad_range(vith_trainer t, uint64_t stage, uint64_t *offset, uint
 int vith_step_update(vith_trainer t, float lr, float grad_scale) {
   return guard([&] {
     TrainerState *s = T(t);
+    if (auto *r = s->exchange()) r->finish();
     auto p = s->model->vit.getParameters();
     auto g = s->model->vit.getGradients();
     s->adam.setLearningRate(lr);
