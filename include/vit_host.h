@@ -124,6 +124,10 @@ int vith_forward_trace(vith_model m, const float *x_dev, uint64_t B, float *acts
 /* backward from dlogits_dev {B,K} (VisionTransformer::backward); dacts_dev (optional) receives
  * (L+1) x {B,N,D}: gradient w.r.t. the final-norm input, then each block's input, last block first */
 int vith_backward(vith_model m, const float *dlogits_dev, uint64_t B, float *dacts_dev);
+/* the same backward, returning what VisionTransformer::backward returns: the image gradient
+ * {B,C,H,W} (src/model/VisionTransformer.cpp:68; in the reference patch mode every patch carries
+ * patch 0 of image 0, src/layers/PatchEmbedding.cpp:86-94; training steps skip this gradient) */
+int vith_backward_image(vith_model m, const float *dlogits_dev, uint64_t B, float *dimage_dev);
 /* top-1: first index of the row maximum of softmax(logits) (app/test.cpp:92-112) */
 int vith_predict(vith_model m, const float *x_dev, uint64_t B, int32_t *pred_dev);
 
@@ -153,6 +157,16 @@ int vith_fit_augmented(vith_model m, const float *x, const float *y_onehot, uint
                        const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
                        float weight_decay, float warmup_frac, const vith_augment_config *augment, uint32_t augment_seed,
                        float *history);
+
+/* Trainer::train with a TrainerConfig as app/main.cpp builds it (app/main.cpp:21-27: only epochs,
+ * batch size, lr_init, weight decay and warm-up fraction set): in particular every training batch
+ * is augmented with the reference's probabilities, as its train_epoch does unconditionally
+ * (src/model/Trainer.cpp:156-161, 198-201), the engine seeded from the process's host generator
+ * (vith_next_seed draws from it: after vith_seed(s) the sequence is repeatable). */
+int vith_fit_reference_defaults(vith_model m, const float *x, const float *y_onehot, uint64_t n, const float *x_test,
+                                const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size,
+                                float lr_init, float weight_decay, float warmup_frac, float *history);
+uint64_t vith_next_seed(void);
 
 /* ---- trainer: the per-batch body of Trainer::train_epoch (src/model/Trainer.cpp:201-227) ---- */
 vith_trainer vith_trainer_create(vith_model m, float beta1, float beta2, float eps, float weight_decay,

@@ -257,6 +257,15 @@ enum { VITK_PATCH_REFERENCE = 0, VITK_PATCH_IM2COL = 1 };
 int vitk_patch_gather(const float *img, int32_t B, int32_t C, int32_t HW, int32_t P, int32_t mode, float *patches,
                       vitk_stream_t stream);
 
+/* Its backward (src/layers/PatchEmbedding.cpp:74-103): the image gradient dimg [B][C][HW][HW] from
+ * the patch-row gradients dpatches [B*Np][P*P*C] (= dY W^T of the projection).  VITK_PATCH_IM2COL:
+ * each pixel takes element (c, i, j) of its own patch's row.  VITK_PATCH_REFERENCE: the
+ * reference reads every patch's row through a pointer that ignores the row offset (:86-87), so all
+ * patches of all images receive row 0; reproduced as is.  (Trainer discards this gradient,
+ * src/model/Trainer.cpp:212.) */
+int vitk_patch_scatter_bwd(const float *dpatches, int32_t B, int32_t C, int32_t HW, int32_t P, int32_t mode,
+                           float *dimg, vitk_stream_t stream);
+
 /* ---- embeddings (src/layers/Embeddings.cpp:24-40 forward, :42-74 backward) --------------------
  * assemble: out[b][0][:] = cls + pos[0]; out[b][1+p][:] = proj[b*Np+p][:] + pos[1+p].
  * split (backward): dproj[b*Np+p][:] = dy[b][1+p][:]   (dpos/dcls come from vitk_colsum_f32 over

@@ -465,6 +465,29 @@ static void embeddings_backward(uint64_t img, uint64_t P, uint64_t C, uint64_t D
   free(gp);
 }
 
+/* The image gradient Embeddings::backward returns (src/layers/Embeddings.cpp:57-73 ->
+ * PatchEmbedding::backward, src/layers/PatchEmbedding.cpp:65-104): dpatches = dY[:,1:,:] W^T, then
+ * the "un-patch" loop -- which takes every patch's row through getData(), a pointer that ignores
+ * the slice offset (:86-87), so the (c, h, w)-ordered values written into every patch of every
+ * image are those of row 0 (patch 0 of image 0). */
+void vo_embeddings_input_grad(uint64_t img, uint64_t P, uint64_t C, uint64_t D, const float *params, uint64_t B,
+                              const float *dy, float *dimg) {
+  const uint64_t nph = img / P, np = nph * nph, N = np + 1, pd = P * P * C;
+  const float *W = params;
+  float *gp = falloc(B * np * D), *dpatch = falloc(B * np * pd), *dW = falloc(pd * D), *db = falloc(D);
+  float *zeros = falloc(B * np * pd);
+  for (uint64_t bi = 0; bi < B; ++bi) memcpy(gp + bi * np * D, dy + (bi * N + 1) * D, np * D * sizeof(float));
+  vo_dense_backward(zeros, gp, B * np, pd, D, W, dW, db, dpatch);
+  for (uint64_t b = 0; b < B; ++b)
+    for (uint64_t ph = 0; ph < nph; ++ph)
+      for (uint64_t pw = 0; pw < nph; ++pw)
+        for (uint64_t c = 0; c < C; ++c)
+          for (uint64_t h = 0; h < P; ++h)
+            for (uint64_t w = 0; w < P; ++w)
+              dimg[((b * C + c) * img + ph * P + h) * img + pw * P + w] = dpatch[c * P * P + h * P + w];
+  free(gp); free(dpatch); free(dW); free(db); free(zeros);
+}
+
 void vo_embeddings(uint64_t img, uint64_t P, uint64_t C, uint64_t D, const float *params, const float *x, uint64_t B,
                    const float *dy, float *y, float *grads) {
   float *patches = NULL;

@@ -62,6 +62,11 @@ void vo_patch_gather(const float *img, uint64_t B, uint64_t C, uint64_t HW, uint
 void vo_embeddings(uint64_t img, uint64_t P, uint64_t C, uint64_t D, const float *params, const float *x, uint64_t B,
                    const float *dy, float *y, float *grads);
 
+/* image gradient {B,C,img,img} that Embeddings::backward returns (row 0 of the patch gradients
+ * un-patched into every patch: src/layers/PatchEmbedding.cpp:86-94) */
+void vo_embeddings_input_grad(uint64_t img, uint64_t P, uint64_t C, uint64_t D, const float *params, uint64_t B,
+                              const float *dy, float *dimg);
+
 /* ---- loss / optimiser / schedule ---- */
 float vo_cross_entropy(const float *logits, const float *y, uint64_t B, uint64_t K, const float *w, uint64_t n_w,
                        float *grad);

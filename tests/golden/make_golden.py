@@ -196,6 +196,18 @@ def augment():
     np.savez_compressed(os.path.join(G, "augment.npz"), **out)
 
 
+def embed_input_grad():
+    """The image gradient Embeddings::backward returns for the three embedding cases of ops.npz."""
+    out = {}
+    for tag in ("emb_a", "emb_b", "emb_c"):
+        c = V.op_case(tag)
+        y, g_ = V.f32(c["B"], c["N"], c["D"]), V.f32(c["n"])
+        dimg = V.f32(c["B"], c["C"], c["img"], c["img"])
+        R.vref_embeddings(c["img"], c["P"], c["C"], c["D"], c["prm"], c["x"], c["B"], c["dy"], y, g_, dimg)
+        out[tag] = dimg
+    np.savez_compressed(os.path.join(G, "embed_input_grad.npz"), **out)
+
+
 def dropout():
     """The reference at dropout 0.2 (its own default, app/main.cpp:19).  Its masks come from a
     random_device-seeded engine, so each run below is unrepeatable; the masks it drew are read
@@ -248,12 +260,16 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["augment"]:
         augment()
         sys.exit(0)
+    if sys.argv[1:] == ["embed_input_grad"]:
+        embed_input_grad()
+        sys.exit(0)
     if sys.argv[1:] == ["dropout"]:
         dropout()
         sys.exit(0)
     ops()
     augment()
     dropout()
+    embed_input_grad()
     for name, (cfgd, B, seed, steps, full) in V.MODEL_CASES.items():
         model_case(name, cfgd, B, seed, steps, full)
     shipped_checkpoint()

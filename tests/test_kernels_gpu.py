@@ -198,6 +198,34 @@ def test_layernorm_golden_and_strided_rows(K):
     assert (out[:, 1:] == 0).all()
 
 
+def test_gemm_operand_of_more_than_4_gib(K):
+    """A k-contiguous operand whose rows span more than 4 GiB (M * lda * 4 bytes > 2^32): the buffer
+    descriptors of the unguarded path are 32-bit, so they must cover one tile, not the rest of
+    the operand.  Checked on the first and last row tiles against float64."""
+    M, Kc, N, lda = (1 << 20) + 128, 64, 128, 1040
+    assert M * lda * 4 > 1 << 32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.zeros(M * lda, dtype=torch.float32, device="cuda").view(M, lda)
+    A[:256, :Kc] = torch.randn(256, Kc, device="cuda", generator=g)
+    A[-256:, :Kc] = torch.randn(256, Kc, device="cuda", generator=g)
+    Bm = torch.randn(Kc, N, device="cuda", generator=g)
+    Cm = torch.full((M, N), 7.0, device="cuda")
+    K.gemm(A, Bm, Cm, M, N, Kc, lda=lda)
+    torch.cuda.synchronize()
+    for sl in (slice(0, 256), slice(M - 256, M)):
+        want = A[sl, :Kc].double() @ Bm.double()
+        close(host(Cm[sl]), want.cpu().numpy(), 2e-6)
+    assert float(Cm[300:M - 300].abs().max()) == 0.0
+    # the same rows as the transposed B operand (C = X A^T): N side of the descriptor
+    X = torch.randn(128, Kc, device="cuda", generator=g)
+    Ct = torch.empty(128, M, device="cuda")
+    K.gemm(X, A, Ct, 128, M, Kc, trans_b=True, ldb=lda)
+    torch.cuda.synchronize()
+    want = X.double() @ A[M - 256:, :Kc].double().T
+    close(host(Ct[:, M - 256:]), want.cpu().numpy(), 2e-6)
+    del A, Cm, Ct
+
+
 # ------------------------------------------------------------------ element-wise kernels
 @pytest.mark.parametrize("n", [1, 7, 2048, 100003])
 def test_gelu_vs_oracle(K, n):

@@ -111,7 +111,9 @@ def test_layers_match_reference_golden(H):
         L = H.Layer("embeddings", c["img"], c["P"], c["C"], c["D"])
         L.set_params(c["prm"])
         close(L.forward(c["x"], (c["B"], c["N"], c["D"])), g[f"{tag}_y"], 1e-5, tag + " y")
-        L.backward(c["dy"])
+        # backward returns the image gradient, with the reference's quirk (every patch = patch 0 of image 0)
+        dimg = L.backward(c["dy"], (c["B"], c["C"], c["img"], c["img"]))
+        close(dimg, V.golden("embed_input_grad.npz")[tag], 1e-5, tag + " image gradient")
         gr = L.get_grads()
         pd, D, N = c["pd"], c["D"], c["N"]
         off = 0
@@ -412,7 +414,7 @@ def test_im2col_mode_reads_true_patches_and_exact_dk_matches_autograd(H):
     D, Hd, L, K, N, P = c.embedding_dim, c.mlp_hidden_dim, c.num_layers, c.num_classes, c.tokens, c.patch_size
     ps = [torch.tensor(prm[o:o + int(np.prod(s))].reshape(s), dtype=torch.float64, requires_grad=True)
           for o, s in zip(np.cumsum([0] + [int(np.prod(s)) for s in V.param_shapes(c)])[:-1], V.param_shapes(c))]
-    xt = torch.tensor(x, dtype=torch.float64)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     B = xt.shape[0]
     npw = 28 // P
     patches = xt.reshape(B, 3, npw, P, npw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, npw * npw, 3 * P * P)
@@ -448,6 +450,12 @@ def test_im2col_mode_reads_true_patches_and_exact_dk_matches_autograd(H):
         e = V.max_relerr(grads[off:off + k], p_.grad.numpy().ravel(), floor=1e-5)
         assert e <= GRAD_TOL, f"autograd grad tensor {i}: {e:.3e}"
         off += k
+    # VisionTransformer::backward's return value in im2col mode is the true image gradient
+    probs = torch.softmax(logits.detach(), 1).numpy()
+    dlogits = ((probs - V.onehot(lab, K)) / B).astype(np.float32)
+    im.forward(dev(x), training=True)
+    dimg = host_np(im.backward_image(dev(dlogits)))
+    close(dimg, xt.grad.numpy(), GRAD_TOL, "image gradient vs autograd")
 
 
 @pytest.mark.parametrize("name,B", [("C1", 128), ("C2", 64), ("C3", 3), ("C4", 1), ("C5", 2)])
@@ -729,6 +737,37 @@ def test_fit_reproduces_the_reference_epoch_loop(H, tmp_path, monkeypatch, augme
     V.check_digest(m.get_params(), V.param_shapes(ocfg), *V.tensor_digest(p, V.param_shapes(ocfg)), 5e-5,
                    "parameters after two epochs")
     assert os.path.exists("vit_results.csv")
+
+
+def test_default_trainer_config_augments_like_the_reference(H, tmp_path, monkeypatch):
+    """A TrainerConfig as app/main.cpp builds it (augment fields untouched) augments every training
+    batch with the reference's probabilities (src/model/Trainer.cpp:156-161, 198-201), seeded from
+    the host generator: the run equals the explicitly augmented one with that seed -- which
+    test_fit_reproduces_the_reference_epoch_loop[True] pins to the oracle's draws -- and differs from
+    the unaugmented one."""
+    monkeypatch.chdir(tmp_path)
+    ocfg = V.Cfg.make(**V.TINY)
+    K = ocfg.num_classes
+    x, y = V.rng_normal(41, 40, 1, 28, 28), V.onehot(np.random.default_rng(42).integers(0, K, 40), K)
+    xt, yt = V.rng_normal(43, 16, 1, 28, 28), V.onehot(np.random.default_rng(44).integers(0, K, 16), K)
+    prm = V.init_params(ocfg, 45)
+    H.seed(2024)
+    want_seed = H.next_seed() & 0xFFFFFFFF
+    assert want_seed != 0
+    runs = []
+    for mode in ("defaults", "explicit", "off"):
+        m = H.Model(hcfg(H, V.TINY))
+        m.set_params(prm)
+        if mode == "defaults":
+            H.seed(2024)
+            m.fit_reference_defaults(x, y, xt, yt, 2, 16, 1e-3, 1e-4, 0.1)
+        elif mode == "explicit":
+            m.fit(x, y, xt, yt, 2, 16, 1e-3, 1e-4, 0.1, augment=H.AugmentConfig.make(), augment_seed=want_seed)
+        else:
+            m.fit(x, y, xt, yt, 2, 16, 1e-3, 1e-4, 0.1)
+        runs.append(m.get_params())
+    np.testing.assert_array_equal(runs[0], runs[1])
+    assert np.abs(runs[0] - runs[2]).max() > 1e-5
 
 
 def test_long_sequences_fall_back_to_the_unfused_attention_path(H):

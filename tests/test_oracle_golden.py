@@ -212,3 +212,12 @@ def test_dropout_golden():
     O.vo_session_get_params(s, p)
     V.check_digest(p, shapes, g["p_sums"], g["p_norms"], g["p_samples"], 1e-5, "param after Adam")
     O.vo_session_destroy(s)
+
+
+def test_embeddings_image_gradient_golden():
+    g = V.golden("embed_input_grad.npz")
+    for tag in ("emb_a", "emb_b", "emb_c"):
+        c = V.op_case(tag)
+        dimg = V.f32(c["B"], c["C"], c["img"], c["img"])
+        O.vo_embeddings_input_grad(c["img"], c["P"], c["C"], c["D"], c["prm"], c["B"], c["dy"], dimg)
+        np.testing.assert_array_equal(dimg, g[tag])

@@ -124,6 +124,12 @@ def test_embeddings(img, P, C, D, B):
     O.vo_embeddings(img, P, C, D, prm, x, B, dy, y, g)
     R.vref_embeddings(img, P, C, D, prm, x, B, dy, y2, g2, dimg)
     same(y, y2); same(g, g2)
+    # the image gradient the reference returns (and its Trainer drops): patch 0 of image 0 everywhere
+    dimg_o = V.f32(B, C, img, img)
+    O.vo_embeddings_input_grad(img, P, C, D, prm, B, dy, dimg_o)
+    same(dimg_o, dimg)
+    assert np.abs(dimg).max() > 0
+    np.testing.assert_array_equal(dimg[0, :, :P, :P], dimg[B - 1, :, img - P:, img - P:])
 
 
 def test_cross_entropy_adam_schedule_argmax():

@@ -111,6 +111,7 @@ _ORACLE_SIGS = {
     "vo_session_train_step_masked": "Pppufppp>f",
     "vo_patch_gather": "puuuup>v",
     "vo_embeddings": "uuuuppuppp>v",
+    "vo_embeddings_input_grad": "uuuupupp>v",
     "vo_cross_entropy": "ppuupup>f",
     "vo_adam_update": "ppppufffffff>v",
     "vo_cosine_warmup_lr": "lllf>f",

@@ -28,6 +28,29 @@ __global__ void patch_gather_kernel(const float *__restrict__ img, int B, int C,
   }
 }
 
+// Backward of the patch extraction ("un-patch"): the image gradient from the patch-row gradients
+// dpatches [B*Np][P*P*C].  Every image pixel belongs to exactly one patch (stride = patch size),
+// so this is a pure gather per pixel.  VITK_PATCH_IM2COL: pixel (b, c, ph*P+i, pw*P+j) takes
+// element (c, i, j) of its own patch's row.  VITK_PATCH_REFERENCE: what the reference does
+// (src/layers/PatchEmbedding.cpp:86-94) -- it takes the row pointer through getData(), which ignores
+// the slice offset, so EVERY patch of EVERY image receives row 0 (patch 0 of image 0), laid out
+// with the (c, i, j) geometry.
+__global__ void patch_scatter_kernel(const float *__restrict__ dpatches, int B, int C, int HW, int P, int mode,
+                                     float *__restrict__ dimg) {
+  const int np = HW / P;
+  const long long img_sz = (long long)C * HW * HW, total = (long long)B * img_sz;
+  const long long pd = (long long)P * P * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / img_sz;
+    const int c = (int)((i % img_sz) / ((long long)HW * HW));
+    const int y = (int)((i / HW) % HW), x = (int)(i % HW);
+    const int ph = y / P, ii = y % P, pw = x / P, jj = x % P;
+    const long long row = mode == VITK_PATCH_REFERENCE ? 0 : (b * np + ph) * np + pw;
+    dimg[i] = dpatches[row * pd + ((long long)c * P + ii) * P + jj];
+  }
+}
+
 // dst[r][:] = src[index[r]][:]
 __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ index, long long rows,
                                    long long row_len, float *__restrict__ dst) {
@@ -162,6 +185,18 @@ int vitk_patch_gather(const float *img, int32_t B, int32_t C, int32_t HW, int32_
   hipLaunchKernelGGL(patch_gather_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream), img,
                      B, C, HW, P, mode, patches);
   return vitk::check_launch("vitk_patch_gather");
+}
+
+int vitk_patch_scatter_bwd(const float *dpatches, int32_t B, int32_t C, int32_t HW, int32_t P, int32_t mode,
+                           float *dimg, vitk_stream_t stream) {
+  VITK_REQUIRE(B >= 0 && C > 0 && HW > 0 && P > 0 && HW % P == 0, "vitk_patch_scatter_bwd: bad shape");
+  VITK_REQUIRE(mode == VITK_PATCH_REFERENCE || mode == VITK_PATCH_IM2COL, "vitk_patch_scatter_bwd: unknown mode %d", mode);
+  if (B == 0) return 0;
+  VITK_REQUIRE(dpatches && dimg, "vitk_patch_scatter_bwd: null pointer");
+  const long long total = (long long)B * C * HW * HW;
+  hipLaunchKernelGGL(patch_scatter_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     dpatches, B, C, HW, P, mode, dimg);
+  return vitk::check_launch("vitk_patch_scatter_bwd");
 }
 
 int vitk_embed_assemble(const float *proj, const float *cls, const float *pos, int32_t B, int32_t Np, int32_t D,

@@ -126,9 +126,12 @@ struct KContig {
   }
   __device__ static long long origin(long long ld, int row0, int k0) { return (long long)row0 * ld + k0; }
   __device__ static long long slab_bytes(long long) { return BK * 4; }
-  // bytes from the origin to the end of the operand: `rows` rows of which the last holds `ks` k
+  // bytes from the tile origin to the end of what the tile may read: its own rows only (at most
+  // ROWS of the `rows` that remain, so the 32-bit extent cannot wrap however large the operand
+  // is), of which the last holds `ks` k
   __device__ static unsigned extent_bytes(long long ld, int rows, int ks) {
-    return (unsigned)(((long long)(rows - 1) * ld + ks) * 4);
+    const int r = rows < ROWS ? rows : ROWS;
+    return (unsigned)(((long long)(r - 1) * ld + ks) * 4);
   }
   __device__ static void store(float *__restrict__ s, const f32x4 (&reg)[NL]) {
 #pragma unroll

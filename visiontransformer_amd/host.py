@@ -79,6 +79,7 @@ SIGNATURES = {
     "vith_forward": (_int, [_p, _p, _u64, _int, _p]),
     "vith_forward_trace": (_int, [_p, _p, _u64, _p, _p]),
     "vith_backward": (_int, [_p, _p, _u64, _p]),
+    "vith_backward_image": (_int, [_p, _p, _u64, _p]),
     "vith_predict": (_int, [_p, _p, _u64, _p]),
     "vith_trainer_create": (_p, [_p, _f, _f, _f, _f, _p, _u64]),
     "vith_trainer_destroy": (None, [_p]),
@@ -89,6 +90,9 @@ SIGNATURES = {
     "vith_fit": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float, _p]),
     "vith_fit_augmented": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float, _p,
                                   C.c_uint32, _p]),
+    "vith_fit_reference_defaults": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float,
+                                           _p]),
+    "vith_next_seed": (_u64, []),
     "vith_augment": (_int, [_p, C.c_uint32, _p, _u64, _u64, _u64, _u64, _p]),
     "vith_trainer_save_state": (_int, [_p, C.c_char_p]),
     "vith_trainer_load_state": (_int, [_p, C.c_char_p]),
@@ -270,6 +274,10 @@ def dropout_masks(rate, seed_, offset, counts):
     return out
 
 
+def next_seed():
+    return dll().vith_next_seed()
+
+
 def synchronize():
     _check(dll().vith_synchronize())
 
@@ -378,6 +386,16 @@ class Model:
                                         hist.ctypes.data))
         return hist
 
+    def fit_reference_defaults(self, x, y, x_test, y_test, epochs, batch_size, lr_init=3e-4, weight_decay=1e-4,
+                               warmup_frac=0.1):
+        """Trainer::train with a default-constructed TrainerConfig (augmentation on, as in the reference)."""
+        x, y, x_test, y_test = (np.ascontiguousarray(a, np.float32) for a in (x, y, x_test, y_test))
+        hist = np.zeros((epochs, 4), np.float32)
+        _check(dll().vith_fit_reference_defaults(self.h, x.ctypes.data, y.ctypes.data, x.shape[0], x_test.ctypes.data,
+                                                 y_test.ctypes.data, x_test.shape[0], epochs, batch_size, lr_init,
+                                                 weight_decay, warmup_frac, hist.ctypes.data))
+        return hist
+
     def save_weights(self, path):
         _check(dll().vith_save_weights(self.h, os.fsencode(path)))
 
@@ -409,6 +427,14 @@ class Model:
                                 device=dlogits.device)
         _check(dll().vith_backward(self.h, dlogits.data_ptr(), B, dacts.data_ptr() if trace else None))
         return dacts
+
+    def backward_image(self, dlogits):
+        """VisionTransformer::backward's return value: the gradient w.r.t. the input images."""
+        import torch
+        B, c = dlogits.shape[0], self.cfg
+        out = torch.empty(B, c.in_channels, c.image_size, c.image_size, dtype=torch.float32, device=dlogits.device)
+        _check(dll().vith_backward_image(self.h, dlogits.data_ptr(), B, out.data_ptr()))
+        return out
 
     def predict(self, x):
         import torch

@@ -26,11 +26,16 @@ public:
   size_t getNumPatches() const { return num_patches; }
   static void setDefaultPatchMode(int mode);
   void setPatchMode(int mode) { patch_mode = mode; }
+  // backward() returns the image gradient {B,C,H,W} like the reference's; a caller that drops it
+  // (the training step: src/model/Trainer.cpp:212) turns its computation off and gets an undefined
+  // tensor back.
+  void setNeedInputGradient(bool need) { need_input_grad = need; }
 
 private:
   size_t image_height, image_width, patch_size, in_channels, embedding_dim;
   size_t patch_dim, num_patches, num_patches_h, num_patches_w;
   int patch_mode;
+  bool need_input_grad = true;
   std::unique_ptr<Dense> projectionLayer;
 };
 

@@ -2,7 +2,7 @@
 // with the per-epoch mt19937(epoch) shuffle, cosine/warm-up schedule, Adam(L2), CSV log.  The
 // reference augments every training batch with hard-wired probabilities from a random_device
 // seeded engine (src/model/Trainer.cpp:156-161, 198-201); here that is TrainerConfig::augment,
-// off by default, with a seed so that runs can be repeated.
+// on by default like the reference, with an optional seed so that runs can be repeated.
 #ifndef TRAINER_HPP
 #define TRAINER_HPP
 
@@ -26,7 +26,7 @@ struct TrainerConfig {
   float weight_decay = 0.01f;
   float lr_init = 3e-4f;
   float warmup_frac = 0.1f;
-  // Extensions (empty / 0 = the reference's behaviour).
+  // Extensions (the defaults are the reference's behaviour).
   // best_weights_path: after each epoch, save the weights when the test accuracy is a new best and
   // above the epoch's training accuracy (the policy of cuda_Vit/src/model/Trainer.cu:104-108).
   std::string best_weights_path;
@@ -37,8 +37,11 @@ struct TrainerConfig {
   int start_epoch = 0;
   // augment: apply DataAugmentation (probabilities 0.5 / 0.5 / 0.5 and the Config defaults, as
   // src/model/Trainer.cpp:157-161) to every training batch, on the device, folded into the batch
-  // gather.  One engine per epoch, as in the reference, seeded with augment_seed + epoch.
-  bool augment = false;
+  // gather.  On by default: the reference's train_epoch augments unconditionally.  One engine per
+  // epoch, as in the reference, seeded with augment_seed + epoch; augment_seed 0 = take one from
+  // the process's host generator (vit::next_seed(): random_device-seeded like the reference's
+  // engine unless vit::seed() was called).
+  bool augment = true;
   uint32_t augment_seed = 0;
   DataAugmentation::Config augment_config;
   // Data parallelism (one process per GPU).  When a communicator exists (vit::comm_init_*; the

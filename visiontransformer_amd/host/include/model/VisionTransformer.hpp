@@ -48,6 +48,11 @@ public:
   size_t numBackwardStages() const { return encoder_blocks.size() + 2; }
   void backwardBegin(const Tensor &outputGradient);
   void backwardStage(size_t stage);
+  // backward() returns the image gradient {B,C,H,W} (src/model/VisionTransformer.cpp:68); the staged
+  // form used by training steps skips it unless asked.  setDiscardInputGradient(true) lets a
+  // caller of backward() that drops the result (Trainer, src/model/Trainer.cpp:212) skip it too.
+  void setStageInputGradient(bool want) { wantInputGradient = want; }
+  void setDiscardInputGradient(bool discard) { discardInputGradient = discard; }
   // [offset, offset+count) of the gradient arena finalised by `stage`
   void stageGradientRange(size_t stage, size_t *offset, size_t *count) const;
   // token stream after embeddings / each block / final norm of the last forward ((L+2) tensors),
@@ -74,6 +79,7 @@ private:
   Tensor final_norm_output;
   Tensor stageGrad;
   bool trace = false;
+  bool wantInputGradient = false, discardInputGradient = false;
   std::vector<Tensor> traceActs, traceGrads;
 };
 

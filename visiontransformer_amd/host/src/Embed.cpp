@@ -46,10 +46,16 @@ Tensor PatchEmbedding::forward(const Tensor &input, bool isTraining) {
 Tensor PatchEmbedding::backward(const Tensor &outputGradient) {
   const size_t B = outputGradient.getShape()[0];
   Tensor g2 = outputGradient.dense().reshape({B * num_patches, embedding_dim});
-  // parameter gradients only: the image gradient is never consumed (the reference's Trainer drops
-  // the return value of model.backward, src/model/Trainer.cpp:212)
-  projectionLayer->backwardFused(g2, VITK_ACT_NONE, nullptr, false);
-  return Tensor();
+  if (!need_input_grad) {  // parameter gradients only
+    projectionLayer->backwardFused(g2, VITK_ACT_NONE, nullptr, false);
+    return Tensor();
+  }
+  Tensor dpatches = projectionLayer->backwardFused(g2, VITK_ACT_NONE, nullptr, true);
+  Tensor dimg = Tensor::deviceEmpty({B, in_channels, image_height, image_width});
+  vit::check(vitk_patch_scatter_bwd(dpatches.deviceData(), (int32_t)B, (int32_t)in_channels, (int32_t)image_height,
+                                    (int32_t)patch_size, patch_mode, dimg.deviceDataOverwrite(), S()),
+             "vitk_patch_scatter_bwd");
+  return dimg;
 }
 
 std::vector<Tensor *> PatchEmbedding::getParameters() { return projectionLayer->getParameters(); }

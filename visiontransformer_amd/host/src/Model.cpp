@@ -133,6 +133,7 @@ void VisionTransformer::backwardStage(size_t stage) {
   } else if (stage <= L) {
     stageGrad = encoder_blocks[L - stage].backward(stageGrad);
   } else if (stage == L + 1) {
+    embeddings.getPatcher().setNeedInputGradient(wantInputGradient);
     stageGrad = embeddings.backward(stageGrad);
     return;
   } else {
@@ -159,7 +160,13 @@ void VisionTransformer::stageGradientRange(size_t stage, size_t *offset, size_t 
 
 Tensor VisionTransformer::backward(const Tensor &outputGradient) {
   backwardBegin(outputGradient);
-  for (size_t s = 0; s < numBackwardStages(); ++s) backwardStage(s);
+  const bool staged_default = wantInputGradient;
+  wantInputGradient = true;  // Layer::backward returns the input gradient, as in the reference
+  for (size_t s = 0; s < numBackwardStages(); ++s) {
+    if (s + 1 == numBackwardStages() && discardInputGradient) wantInputGradient = false;
+    backwardStage(s);
+  }
+  wantInputGradient = staged_default;
   Tensor out = stageGrad;
   stageGrad = Tensor();
   return out;

@@ -29,6 +29,11 @@ Trainer::Trainer(VisionTransformer &model, const TrainerConfig &train_config, co
     : model(model), optimizer(train_config.learning_rate, 0.9f, 0.999f, 1e-8f, train_config.weight_decay), loss_fn(),
       config(train_config), logger(log_path()) {
   loss_fn.setClassWeights(class_weights);
+  if (config.augment && config.augment_seed == 0) {
+    do config.augment_seed = static_cast<uint32_t>(vit::next_seed());
+    while (config.augment_seed == 0);
+  }
+  model.setDiscardInputGradient(true);  // trainStep drops what model.backward returns (src/model/Trainer.cpp:212)
   if (vit::comm_active()) {
     reducer = std::make_unique<vit::GradientReducer>(model, config.bucket_bytes);
     // replicas start from rank 0's parameters (each process initialised its own)

@@ -280,6 +280,16 @@ int vith_backward(vith_model m, const float *dlogits_dev, uint64_t B, float *dac
   });
 }
 
+int vith_backward_image(vith_model m, const float *dlogits_dev, uint64_t B, float *dimage_dev) {
+  return guard([&] {
+    VisionTransformer &v = M(m)->vit;
+    if (!dimage_dev) throw std::invalid_argument("vith_backward_image: null output");
+    Tensor g = Tensor::wrapDevice(const_cast<float *>(dlogits_dev), {(size_t)B, v.getConfig().num_classes});
+    Tensor dimg = v.backward(g);
+    copy_out(dimg, dimage_dev);
+  });
+}
+
 int vith_predict(vith_model m, const float *x_dev, uint64_t B, int32_t *pred_dev) {
   return guard([&] {
     Tensor logits = M(m)->vit.forward(M(m)->input(x_dev, B), false);
@@ -385,8 +395,8 @@ int vith_fit_augmented(vith_model m, const float *x, const float *y, uint64_t n,
     tc.learning_rate = lr_init;
     tc.weight_decay = weight_decay;
     tc.warmup_frac = warmup_frac;
+    tc.augment = augment != nullptr;
     if (augment) {
-      tc.augment = true;
       tc.augment_seed = augment_seed;
       tc.augment_config = to_aug(augment);
     }
@@ -398,6 +408,33 @@ int vith_fit_augmented(vith_model m, const float *x, const float *y, uint64_t n,
       for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
   });
 }
+int vith_fit_reference_defaults(vith_model m, const float *x, const float *y, uint64_t n, const float *x_test,
+                                const float *y_test, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
+                                float weight_decay, float warmup_frac, float *history) {
+  return guard([&] {
+    VisionTransformer &v = M(m)->vit;
+    const ViTConfig &c = v.getConfig();
+    const size_t sample = c.in_channels * c.image_size * c.image_size, K = c.num_classes;
+    auto wrap = [&](const float *px, const float *py, uint64_t rows) {
+      return std::make_pair(
+          Tensor({(size_t)rows, c.in_channels, c.image_size, c.image_size}, std::vector<float>(px, px + rows * sample)),
+          Tensor({(size_t)rows, K}, std::vector<float>(py, py + rows * K)));
+    };
+    TrainerConfig tc;  // only the fields app/main.cpp:21-27 sets; everything else as constructed
+    tc.epochs = epochs;
+    tc.batch_size = (size_t)batch_size;
+    tc.lr_init = lr_init;
+    tc.weight_decay = weight_decay;
+    tc.warmup_frac = warmup_frac;
+    Trainer trainer(v, tc);
+    trainer.setQuiet(true);
+    trainer.train(wrap(x, y, n), wrap(x_test, y_test, n_test));
+    const auto &h = trainer.history();
+    for (size_t e = 0; e < h.size() && history; ++e)
+      for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
+  });
+}
+uint64_t vith_next_seed(void) { return vit::next_seed(); }
 int vith_trainer_save_state(vith_trainer t, const char *path) {
   return guard([&] {
     if (!path) throw std::invalid_argument("vith_trainer_save_state: null path");

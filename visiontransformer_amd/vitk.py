@@ -78,6 +78,7 @@ SIGNATURES = {
     "vitk_sdpa_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _i32, _i32, _i32, _i32, _f, _i32, _p, _p, _p, _i64,
                                 _p, _sz, _p]),
     "vitk_patch_gather": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "vitk_patch_scatter_bwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "vitk_embed_assemble": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
     "vitk_embed_split_bwd": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "vitk_cls_gather": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
