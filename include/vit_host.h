@@ -167,6 +167,30 @@ int vith_fit_reference_defaults(vith_model m, const float *x, const float *y_one
                                 const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size,
                                 float lr_init, float weight_decay, float warmup_frac, float *history);
 uint64_t vith_next_seed(void);
+/* vith_fit (no augmentation) with the checkpoint extensions of TrainerConfig, none of which the
+ * reference has (it keeps optimizer state in memory only, src/optimizers/Adam.cpp:22-25):
+ *   best_weights_path  after an epoch whose test accuracy is a new best AND above that epoch's
+ *                      training accuracy, save the weights there (the policy of the reference's
+ *                      CUDA tree, cuda_Vit/src/model/Trainer.cu:104-108); NULL = off
+ *   state_path         after every epoch write state_path + ".weights" and the resumable training
+ *                      state (Adam moments and step count, schedule position, dropout stream
+ *                      position, epochs done, best accuracy) to state_path; NULL = off
+ *   start_epoch        first epoch to run (epochs before it are taken as done)
+ *   stop_epoch         > 0: stop before this epoch although the schedule is laid out for `epochs`
+ *                      (a job that ends early and is resumed later); 0 = run to the end
+ *   resume             non-zero: first load state_path + ".weights" and state_path and continue
+ *                      after the last completed epoch, bit for bit like the uninterrupted run
+ * history rows are written from index 0 for the epochs this call ran. */
+typedef struct vith_fit_options {
+  const char *best_weights_path;
+  const char *state_path;
+  int32_t start_epoch;
+  int32_t resume;
+  int32_t stop_epoch;
+} vith_fit_options;
+int vith_fit_with_options(vith_model m, const float *x, const float *y_onehot, uint64_t n, const float *x_test,
+                          const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
+                          float weight_decay, float warmup_frac, const vith_fit_options *options, float *history);
 
 /* ---- trainer: the per-batch body of Trainer::train_epoch (src/model/Trainer.cpp:201-227) ---- */
 vith_trainer vith_trainer_create(vith_model m, float beta1, float beta2, float eps, float weight_decay,

@@ -41,6 +41,13 @@
 #include "layers/FeedForward.hpp"
 #include "activations/GELU.hpp"
 
+#define TENSOR_SURFACE_FN vref_tensor_scenario
+#include "../tests/tensor_surface.inc"
+#include "utils/DataReader.hpp"
+#define DATA_READER_FN vref_data_reader
+#define CLASS_WEIGHTS_FN vref_class_weights
+#include "../tests/data_reader.inc"
+
 Tensor softmax(const Tensor &logits, int axis);
 Tensor softmax_backward(const Tensor &grad_output, const Tensor &softmax_output);
 

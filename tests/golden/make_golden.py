@@ -208,6 +208,34 @@ def embed_input_grad():
     np.savez_compressed(os.path.join(G, "embed_input_grad.npz"), **out)
 
 
+def tensor_surface():
+    """The Tensor-API scenarios of tests/tensor_surface.inc run on the reference's own Tensor class."""
+    out = {}
+    for sc in range(V.TENSOR_SCENARIOS):
+        out[f"s{sc}"] = V.run_tensor_scenario(R.dll.vref_tensor_scenario, sc)
+    np.savez_compressed(os.path.join(G, "tensor_surface.npz"), **out)
+
+
+def apps():
+    """stdout of the reference's evaluation app (app/test.cpp built against the reference's own
+    sources: oracle/Makefile ref_apps) on a synthetic MNIST-format test set and the shipped
+    vit_mnist_4_8 checkpoint: accuracy, per-class precision / recall / F1, confusion matrix."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(V.ROOT, "oracle", "_ref", "ref_app_test")
+    assert os.path.exists(exe), "make -C oracle ref_apps"
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "data"))
+        os.makedirs(os.path.join(d, "models"))
+        V.write_digit_csv(os.path.join(d, "data", "mnist_test.csv"), V.APP_TEST_ROWS, V.APP_TEST_SEED)
+        for ext in ("json", "weights"):
+            shutil.copyfile(os.path.join(G, f"vit_mnist_4_8.{ext}"), os.path.join(d, "models", f"vit_mnist_4_8.{ext}"))
+        r = subprocess.run([exe], cwd=d, capture_output=True, text=True, check=True)
+    with open(os.path.join(G, "app_test_stdout.txt"), "w") as f:
+        f.write(r.stdout)
+    print(r.stdout)
+
+
 def dropout():
     """The reference at dropout 0.2 (its own default, app/main.cpp:19).  Its masks come from a
     random_device-seeded engine, so each run below is unrepeatable; the masks it drew are read
@@ -263,6 +291,12 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["embed_input_grad"]:
         embed_input_grad()
         sys.exit(0)
+    if sys.argv[1:] == ["tensor_surface"]:
+        tensor_surface()
+        sys.exit(0)
+    if sys.argv[1:] == ["apps"]:
+        apps()
+        sys.exit(0)
     if sys.argv[1:] == ["dropout"]:
         dropout()
         sys.exit(0)
@@ -270,6 +304,8 @@ if __name__ == "__main__":
     augment()
     dropout()
     embed_input_grad()
+    tensor_surface()
+    apps()
     for name, (cfgd, B, seed, steps, full) in V.MODEL_CASES.items():
         model_case(name, cfgd, B, seed, steps, full)
     shipped_checkpoint()

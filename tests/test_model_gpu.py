@@ -593,6 +593,75 @@ def test_saved_state_resumes_bit_for_bit(H, tmp_path):
         t2.load_state(w)
 
 
+def test_trainer_checkpoint_extensions_best_weights_state_and_resume(H, tmp_path, monkeypatch):
+    """TrainerConfig::best_weights_path / state_path / start_epoch through Trainer::train: a run
+    interrupted after two epochs and resumed from its state file ends bit-identical to the
+    uninterrupted run (dropout on: the mask stream position is part of the state), and the
+    best-checkpoint file holds the weights of the epoch the policy of
+    cuda_Vit/src/model/Trainer.cu:104-108 picks (test accuracy a new best and above the epoch's
+    training accuracy)."""
+    monkeypatch.chdir(tmp_path)
+    cfgd = dict(V.TINY, dropout_rate=0.1)
+    ocfg = V.Cfg.make(**cfgd)
+    K = ocfg.num_classes
+    # a learnable task, so that accuracies move: class templates + noise
+    templ = V.rng_normal(5, K, 1, 28, 28)
+    lab, labt = np.random.default_rng(6).integers(0, K, 96), np.random.default_rng(7).integers(0, K, 48)
+    x = (templ[lab] + 0.7 * V.rng_normal(8, 96, 1, 28, 28)).astype(np.float32)
+    xt = (templ[labt] + 0.7 * V.rng_normal(9, 48, 1, 28, 28)).astype(np.float32)
+    y, yt = V.onehot(lab, K), V.onehot(labt, K)
+    prm = V.init_params(ocfg, 10)
+    E, BS, lr = 5, 32, 2e-3
+
+    def fresh():
+        m = H.Model(hcfg(H, cfgd))
+        m.set_params(prm)
+        return m
+
+    H.seed(31)
+    m = fresh()
+    best = str(tmp_path / "best.weights")
+    hist = m.fit_with_options(x, y, xt, yt, E, BS, lr, 1e-4, 0.1, best_weights_path=best)
+    want = m.get_params()
+    # expected best epoch from the history, by the policy
+    best_acc, best_ep = 0.0, None
+    for e in range(E):
+        if hist[e, 3] > best_acc and hist[e, 3] > hist[e, 1]:
+            best_acc, best_ep = hist[e, 3], e
+    assert best_ep is not None, hist  # test accuracy leads training accuracy (dropout) at some epoch
+    # the same 5-epoch plan, stopped after epoch 2 (a preempted job), state written after every epoch
+    H.seed(31)
+    m1 = fresh()
+    st = str(tmp_path / "run.state")
+    h1 = m1.fit_with_options(x, y, xt, yt, E, BS, lr, 1e-4, 0.1, state_path=st, stop_epoch=2)
+    assert os.path.exists(st) and os.path.exists(st + ".weights")
+    np.testing.assert_array_equal(h1[:2], hist[:2])
+    assert not h1[2:].any()
+    # a new process would start like this: other weights, other dropout position -- then resume
+    H.seed(777)
+    m2 = H.Model(hcfg(H, cfgd))
+    h2 = m2.fit_with_options(x, y, xt, yt, E, BS, lr, 1e-4, 0.1, state_path=st, resume=True)
+    np.testing.assert_array_equal(m2.get_params(), want)      # bit for bit the uninterrupted run
+    np.testing.assert_array_equal(h2[:E - 2], hist[2:])       # epochs 2..4
+    # resuming a finished run does nothing; so does start_epoch = epochs
+    m3 = H.Model(hcfg(H, cfgd))
+    h3 = m3.fit_with_options(x, y, xt, yt, E, BS, lr, 1e-4, 0.1, state_path=st, resume=True)
+    np.testing.assert_array_equal(m3.get_params(), want)
+    assert not h3.any()
+    m4 = fresh()
+    m4.fit_with_options(x, y, xt, yt, E, BS, lr, 1e-4, 0.1, start_epoch=E)
+    np.testing.assert_array_equal(m4.get_params(), prm)
+    # the best checkpoint: evaluating it reproduces the chosen epoch's test accuracy
+    mb = fresh()
+    mb.load_weights(best)
+    tb = H.Trainer(mb)
+    ok = 0.0
+    for b in range(0, 48, BS):
+        _, c = tb.eval_batch(dev(xt[b:b + BS]), dev(yt[b:b + BS]))
+        ok += c / len(xt[b:b + BS])
+    assert abs(ok / ((48 + BS - 1) // BS) - best_acc) < 1e-6, (ok, best_acc, best_ep)
+
+
 # ------------------------------------------------- checkpoints written by the reference's CUDA tree
 def read_weights_tensors(path):
     """[(shape, float32 array)] of a .weights file: u64 rank, u64 dims[rank], f32 data per tensor."""

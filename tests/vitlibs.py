@@ -169,6 +169,7 @@ _REF_SIGS = {
     "vref_epoch_order": "uip>v",
     "vref_argmax": "puup>v",
     "vref_augment": "puuuuipp>v",
+    "vref_tensor_scenario": "ippppp>i",
 }
 
 _cache = {}
@@ -474,6 +475,49 @@ AUGMENT_CASES = {
 def augment_case(name):
     B, Cc, H, W, seed, cfg = AUGMENT_CASES[name]
     return dict(B=B, C=Cc, H=H, W=W, seed=seed, cfg=np.array(cfg, np.float32), x=rng_normal(900 + seed, B, Cc, H, W))
+
+
+# ---- Tensor-API scenarios (tests/tensor_surface.inc) -----------------------------------------
+TENSOR_SCENARIOS = 30
+
+
+def tensor_surface_inputs():
+    return rng_normal(77, 4096), rng_normal(78, 4096)
+
+
+def run_tensor_scenario(fn, sc):
+    """fn(scenario, a, b, out, out_shape, out_rank) -> 0 of either build of the scenarios."""
+    a, b = tensor_surface_inputs()
+    out = np.zeros(8192, np.float32)
+    shape = np.zeros(4, np.uint64)
+    rank = np.zeros(1, np.uint64)
+    rc = fn(sc, a.ctypes.data, b.ctypes.data, out.ctypes.data, shape.ctypes.data, rank.ctypes.data)
+    assert rc == 0, (sc, rc)
+    shp = tuple(int(v) for v in shape[:int(rank[0])])
+    return out[:int(np.prod(shp))].reshape(shp).copy()
+
+
+# ---- synthetic MNIST-format CSV for running the reference's applications -----------------------
+def write_digit_csv(path, rows, seed, classes=10):
+    """`label,pixel0..pixel783` with a header line, like the MNIST CSVs the reference's apps read
+    (src/utils/DataReader.cpp:31-75): stroke images whose stroke pattern depends on the label, so a
+    model can learn them; integer pixels 0..255."""
+    rng = np.random.default_rng(seed)
+    lines = ["label," + ",".join(f"pixel{i}" for i in range(784))]
+    for _ in range(rows):
+        lab = int(rng.integers(0, classes))
+        img = rng.integers(0, 40, (28, 28))
+        r0, c0 = 4 + 2 * (lab % 5), 4 + 4 * (lab // 5)
+        dr, dc = (1, 0) if lab % 2 else (0, 1)
+        for t in range(int(rng.integers(8, 14))):
+            rr, cc = min(r0 + dr * t, 27), min(c0 + dc * t, 27)
+            img[max(rr - 1, 0):rr + 2, max(cc - 1, 0):cc + 2] = rng.integers(200, 256)
+        lines.append(str(lab) + "," + ",".join(str(int(v)) for v in img.reshape(-1)))
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+APP_TEST_ROWS, APP_TEST_SEED = 300, 2025
 
 
 def golden(name):

@@ -93,6 +93,8 @@ SIGNATURES = {
     "vith_fit_reference_defaults": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float,
                                            _p]),
     "vith_next_seed": (_u64, []),
+    "vith_fit_with_options": (_int, [_p, _p, _p, _u64, _p, _p, _u64, _int, _u64, C.c_float, C.c_float, C.c_float, _p,
+                                     _p]),
     "vith_augment": (_int, [_p, C.c_uint32, _p, _u64, _u64, _u64, _u64, _p]),
     "vith_trainer_save_state": (_int, [_p, C.c_char_p]),
     "vith_trainer_load_state": (_int, [_p, C.c_char_p]),
@@ -286,6 +288,11 @@ def cosine_warmup_lr(step, warmup, total, lr_max):
     return dll().vith_cosine_warmup_lr(step, warmup, total, lr_max)
 
 
+class FitOptions(C.Structure):
+    _fields_ = [("best_weights_path", C.c_char_p), ("state_path", C.c_char_p), ("start_epoch", C.c_int32),
+                ("resume", C.c_int32), ("stop_epoch", C.c_int32)]
+
+
 class AugmentConfig(C.Structure):
     """DataAugmentation::Config (include/utils/DataAugmentation.hpp:11-19 of the reference)."""
     _fields_ = [(n, C.c_float) for n in ("rotation_prob", "translate_prob", "zoom_prob", "rotation_factor",
@@ -394,6 +401,19 @@ class Model:
         _check(dll().vith_fit_reference_defaults(self.h, x.ctypes.data, y.ctypes.data, x.shape[0], x_test.ctypes.data,
                                                  y_test.ctypes.data, x_test.shape[0], epochs, batch_size, lr_init,
                                                  weight_decay, warmup_frac, hist.ctypes.data))
+        return hist
+
+    def fit_with_options(self, x, y, x_test, y_test, epochs, batch_size, lr_init=3e-4, weight_decay=1e-4,
+                         warmup_frac=0.1, best_weights_path=None, state_path=None, start_epoch=0, resume=False,
+                         stop_epoch=0):
+        """vith_fit with TrainerConfig's checkpoint extensions (see include/vit_host.h)."""
+        x, y, x_test, y_test = (np.ascontiguousarray(a, np.float32) for a in (x, y, x_test, y_test))
+        opt = FitOptions(os.fsencode(best_weights_path) if best_weights_path else None,
+                         os.fsencode(state_path) if state_path else None, start_epoch, int(resume), stop_epoch)
+        hist = np.zeros((epochs, 4), np.float32)
+        _check(dll().vith_fit_with_options(self.h, x.ctypes.data, y.ctypes.data, x.shape[0], x_test.ctypes.data,
+                                           y_test.ctypes.data, x_test.shape[0], epochs, batch_size, lr_init,
+                                           weight_decay, warmup_frac, C.byref(opt), hist.ctypes.data))
         return hist
 
     def save_weights(self, path):

@@ -35,6 +35,9 @@ struct TrainerConfig {
   // state_path + ".weights".  start_epoch: first epoch to run when resuming from such a state.
   std::string state_path;
   int start_epoch = 0;
+  // stop_epoch: when > 0, leave the epoch loop before this epoch although `epochs` (which sets the
+  // length of the learning-rate schedule) is larger -- a job that ends early and is resumed later.
+  int stop_epoch = 0;
   // augment: apply DataAugmentation (probabilities 0.5 / 0.5 / 0.5 and the Config defaults, as
   // src/model/Trainer.cpp:157-161) to every training batch, on the device, folded into the batch
   // gather.  On by default: the reference's train_epoch augments unconditionally.  One engine per
@@ -67,6 +70,7 @@ public:
   float trainStep(const Tensor &X_batch, const Tensor &y_batch, float lr_now, float *accuracy = nullptr);
   std::pair<float, float> evaluate(const Tensor &X_test, const Tensor &y_test);
   void setQuiet(bool q) { quiet = q; }
+  void setStartEpoch(int epoch) { config.start_epoch = epoch; }
   Adam &getOptimizer() { return optimizer; }
   // Everything besides the weights that the next step depends on: Adam's step count and moments,
   // the schedule position (global step, total steps), the dropout stream position and the number

@@ -27,6 +27,40 @@ struct ViTConfig {
   float dropout_rate = 0.1;
 };
 
+// Conversion hooks for nlohmann::json, as include/model/VisionTransformer.hpp:32-57 of the reference
+// has them (same nine keys): found by argument-dependent lookup, so `nlohmann::json j = cfg;` and
+// `j.get<ViTConfig>()` work for an application that uses that library.  Written as templates so
+// this header does not depend on it; when the reference's vendored utils/json.hpp is on the include
+// path it is pulled in and the reference's `json` alias is provided too.
+#if defined(__has_include)
+#if __has_include("utils/json.hpp")
+#include "utils/json.hpp"
+using json = nlohmann::json;
+#endif
+#endif
+
+template <typename Json>
+void to_json(Json &j, const ViTConfig &config) {
+  j = Json{{"image_size", config.image_size},       {"patch_size", config.patch_size},
+           {"in_channels", config.in_channels},     {"num_classes", config.num_classes},
+           {"embedding_dim", config.embedding_dim}, {"num_heads", config.num_heads},
+           {"num_layers", config.num_layers},       {"mlp_hidden_dim", config.mlp_hidden_dim},
+           {"dropout_rate", config.dropout_rate}};
+}
+
+template <typename Json>
+void from_json(const Json &j, ViTConfig &config) {
+  j.at("image_size").get_to(config.image_size);
+  j.at("patch_size").get_to(config.patch_size);
+  j.at("in_channels").get_to(config.in_channels);
+  j.at("num_classes").get_to(config.num_classes);
+  j.at("embedding_dim").get_to(config.embedding_dim);
+  j.at("num_heads").get_to(config.num_heads);
+  j.at("num_layers").get_to(config.num_layers);
+  j.at("mlp_hidden_dim").get_to(config.mlp_hidden_dim);
+  j.at("dropout_rate").get_to(config.dropout_rate);
+}
+
 class VisionTransformer : public Layer {
 public:
   explicit VisionTransformer(const ViTConfig &config);

@@ -109,7 +109,8 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
   const size_t batches_per_epoch = (X_train.getShape()[0] + global_batch - 1) / global_batch;
   const bool root = vit::comm_rank() == 0;
   total_steps = (long long)batches_per_epoch * config.epochs;
-  for (int epoch = config.start_epoch; epoch < config.epochs; ++epoch) {
+  const int last_epoch = config.stop_epoch > 0 ? std::min(config.stop_epoch, config.epochs) : config.epochs;
+  for (int epoch = config.start_epoch; epoch < last_epoch; ++epoch) {
     const auto start = std::chrono::high_resolution_clock::now();
     auto [train_loss, train_acc] = train_epoch(X_train, y_train, epoch);
     if (!quiet) std::cout << "\r" << std::string(80, ' ') << "\r";

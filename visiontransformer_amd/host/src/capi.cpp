@@ -434,6 +434,45 @@ int vith_fit_reference_defaults(vith_model m, const float *x, const float *y, ui
       for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
   });
 }
+int vith_fit_with_options(vith_model m, const float *x, const float *y, uint64_t n, const float *x_test,
+                          const float *y_test, uint64_t n_test, int epochs, uint64_t batch_size, float lr_init,
+                          float weight_decay, float warmup_frac, const vith_fit_options *opt, float *history) {
+  return guard([&] {
+    if (!opt) throw std::invalid_argument("vith_fit_with_options: null options");
+    VisionTransformer &v = M(m)->vit;
+    const ViTConfig &c = v.getConfig();
+    const size_t sample = c.in_channels * c.image_size * c.image_size, K = c.num_classes;
+    auto wrap = [&](const float *px, const float *py, uint64_t rows) {
+      return std::make_pair(
+          Tensor({(size_t)rows, c.in_channels, c.image_size, c.image_size}, std::vector<float>(px, px + rows * sample)),
+          Tensor({(size_t)rows, K}, std::vector<float>(py, py + rows * K)));
+    };
+    TrainerConfig tc;
+    tc.epochs = epochs;
+    tc.batch_size = (size_t)batch_size;
+    tc.lr_init = lr_init;
+    tc.learning_rate = lr_init;
+    tc.weight_decay = weight_decay;
+    tc.warmup_frac = warmup_frac;
+    tc.augment = false;
+    if (opt->best_weights_path) tc.best_weights_path = opt->best_weights_path;
+    if (opt->state_path) tc.state_path = opt->state_path;
+    tc.start_epoch = opt->start_epoch;
+    tc.stop_epoch = opt->stop_epoch;
+    ModelUtils::set_verbose(false);
+    if (opt->resume) {
+      if (tc.state_path.empty()) throw std::invalid_argument("vith_fit_with_options: resume needs state_path");
+      ModelUtils::load_weights(v, tc.state_path + ".weights");
+    }
+    Trainer trainer(v, tc);
+    trainer.setQuiet(true);
+    if (opt->resume) trainer.setStartEpoch(trainer.loadState(tc.state_path));
+    trainer.train(wrap(x, y, n), wrap(x_test, y_test, n_test));
+    const auto &h = trainer.history();
+    for (size_t e = 0; e < h.size() && history; ++e)
+      for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
+  });
+}
 uint64_t vith_next_seed(void) { return vit::next_seed(); }
 int vith_trainer_save_state(vith_trainer t, const char *path) {
   return guard([&] {
