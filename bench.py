@@ -49,6 +49,17 @@ def train_flops_per_image(c):
     return 3 * fwd
 
 
+def executed_train_flops_per_image(c):
+    """The same count when the last encoder block and the final norm work on the CLS token only (the
+    default; vith_set_first_token_tail): its keys / values still come from all tokens, its query,
+    attention row, output projection and feed-forward from one token."""
+    n_p = (c["image_size"] // c["patch_size"]) ** 2
+    n, d, h = n_p + 1, c["embedding_dim"], c["mlp_hidden_dim"]
+    dense_block = 4 * n * d * d + 2 * n * n * d + 2 * n * d * h
+    tail_block = 2 * n * d * d + 2 * d * d + 2 * n * d + 2 * d * h
+    return train_flops_per_image(c) - 3 * 2 * (dense_block - tail_block)
+
+
 def cpu_baseline(cfgd, seconds_budget=30.0):
     """Time the reference CPU path on the host: one training step on a tiny batch of the same model."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -112,6 +123,9 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="initialise RCCL and issue the bucket all-reduces even with one rank (rehearsal of the "
                          "multi-GPU code path on a one-GPU box)")
+    ap.add_argument("--dense-tail", action="store_true",
+                    help="compute every token of the last encoder block as the reference does, instead of only the "
+                         "CLS token that the classification head reads (same results; see include/vit_host.h)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="dropout rate (0 = the headline/parity configuration; 0.1 adds the device RNG cost)")
     args = ap.parse_args()
@@ -136,6 +150,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     host.init(local_rank)
     host.use_torch_stream()
+    host.set_first_token_tail(not args.dense_tail)
 
     cfgd, batch = WORKLOADS[args.workload]
     if args.batch:
@@ -205,7 +220,10 @@ def main():
                        "parallelism": f"dp{world}" + (f" ({trainer.num_buckets()} gradient buckets, ncclAllReduce on a side"
                                                       " HIP stream overlapped with backward)"
                                                       if (world > 1 or args.force_collectives) else ""),
-                       "patch_mode": "im2col", "params": int(model.n), "final_loss": round(float(loss), 6)},
+                       "patch_mode": "im2col", "params": int(model.n), "final_loss": round(float(loss), 6),
+                       "last_block": "all tokens (as the reference)" if args.dense_tail or args.dropout > 0 else
+                                     "CLS token only after its keys/values (the head reads nothing else; same logits, "
+                                     "loss, gradients and updates)"},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": measured_traffic(dom["name"]),
@@ -216,6 +234,11 @@ def main():
                          "all_gemm_ms_per_step": round(gemm_ms / args.steps, 3),
                          "step_frac_of_peak": round(value / world * f_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                          "train_gflop_per_image": round(f_img / 1e9, 2),
+                         "train_gflop_per_image_executed": round((f_img if args.dense_tail or args.dropout > 0 else
+                                                                  executed_train_flops_per_image(cfgd)) / 1e9, 2),
+                         "step_frac_of_peak_executed": round(
+                             value / world * (f_img if args.dense_tail or args.dropout > 0 else
+                                              executed_train_flops_per_image(cfgd)) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                          "gemm_variants": [{"kernel": r["name"], "launches": r["launches"],
                                             "avg_ms": round(r["ms"] / r["launches"], 4),
                                             "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in prof]},

@@ -90,6 +90,14 @@ int vith_dropout_replay(const float *masks_dev, uint64_t count);
  * softmax with the probabilities materialised (the reference's own sequence of operations,
  * src/layers/MultiHeadAttention.cpp:96-156). */
 int vith_set_fused_attention(int on);
+/* The classification head reads only the CLS token of the last encoder block's output
+ * (src/model/VisionTransformer.cpp:27-37) and re-injects a gradient that is zero for every other
+ * token (:49-56).  1 (default): the last block's output projection, residuals, second norm and
+ * feed-forward, the final norm, and their backward run on that one token per sequence (its
+ * attention core on one query row; keys / values still come from all tokens) -- same logits, loss,
+ * parameter gradients and updates, to rounding.  0: every token is computed, as the reference
+ * does.  Applies to forwards from then on; tracing forwards (vith_forward_trace) are always dense. */
+int vith_set_first_token_tail(int on);
 uint64_t vith_device_bytes_in_use(void);
 
 /* ---- model: VisionTransformer (src/model/VisionTransformer.cpp of the reference) ------------ */

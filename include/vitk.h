@@ -174,6 +174,10 @@ int vitk_add_rowvec_f32(float *x, int64_t rows, int64_t cols, const float *v, vi
  * src/core/Tensor.cpp:227-254). */
 int vitk_copy2d_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int64_t rows, int64_t cols,
                     vitk_stream_t stream);
+/* strided 2-D accumulate: dst[r][c] += src[r][c] (a gradient that exists for some rows only, added
+ * into the rows of a full tensor) */
+int vitk_add2d_f32(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                   vitk_stream_t stream);
 /* gather of a strided view of up to 4 dimensions (shape4/strides4 in elements, host arrays of 4;
  * pad leading dimensions with extent 1) into a contiguous buffer: the general form of
  * Tensor::contiguous() for transposed / sliced / stride-0 expanded views. */
@@ -218,6 +222,21 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
                   int64_t ld_out, const float *stats, int32_t B, int32_t H, int32_t N, int32_t dh, float scale,
                   int32_t dk_mode, float *dq, float *dk, float *dv, int64_t ld_dqkv, float *workspace,
                   size_t workspace_bytes, vitk_stream_t stream);
+
+/* The same attention core for ONE query token per (batch, head) -- all that the last encoder block
+ * needs, because only its CLS token reaches the classification head
+ * (src/model/VisionTransformer.cpp:27-37, 49-56).  q / out / dout / dq address element (b, h, d) at
+ * ptr[b*ld + h*dh + d] (one row per batch entry); k, v, dk, dv as in vitk_sdpa_fwd.  stats is
+ * [B*H][2].  The backward writes dk / dv for ALL keys (outer products) and dq for the one row.
+ * Supported: N <= 256, dh <= 64 (vitk_sdpa_row_supported). */
+int vitk_sdpa_row_supported(int32_t N, int32_t dh);
+int vitk_sdpa_row_fwd(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, int32_t B, int32_t H,
+                      int32_t N, int32_t dh, float scale, float *out, int64_t ld_out, float *stats,
+                      vitk_stream_t stream);
+int vitk_sdpa_row_bwd(const float *q, int64_t ld_q, const float *k, const float *v, int64_t ld_kv, const float *out,
+                      const float *dout, int64_t ld_out, const float *stats, int32_t B, int32_t H, int32_t N, int32_t dh,
+                      float scale, int32_t dk_mode, float *dq, int64_t ld_dq, float *dk, float *dv, int64_t ld_dkv,
+                      vitk_stream_t stream);
 
 /* ---- batch assembly: dst[r][:] = src[index[r]][:]  (the per-batch gather of shuffled samples,
  * src/model/Trainer.cpp:163-199, done on the device from a dataset that stays resident in HBM).

@@ -682,6 +682,44 @@ def test_sdpa_fused_matches_float64(K, B, H, N, dh, pad, dk_mode):
     assert not g[:, 3 * D:].any()
 
 
+@pytest.mark.parametrize("B,H,N,dh,pad", [(3, 12, 197, 64, 0), (4, 8, 5, 12, 0), (2, 6, 17, 32, 0), (1, 2, 256, 64, 0),
+                                          (2, 2, 33, 20, 1), (1, 1, 1, 4, 0), (2, 3, 100, 7, 0)])
+@pytest.mark.parametrize("dk_mode", ["reference", "exact"])
+def test_sdpa_single_query_row_matches_float64(K, B, H, N, dh, pad, dk_mode):
+    """vitk_sdpa_row_fwd / _bwd: attention of the first token only (what the last encoder block needs),
+    against the float64 attention with an output gradient that is zero for every other token."""
+    D, M = H * dh, B * N
+    ld = 3 * D + pad
+    qkv = np.zeros((M, ld), np.float32)
+    qkv[:, :3 * D] = V.rng_normal(21, M, 3 * D)
+    do_row = V.rng_normal(22, B, D)
+    do_full = np.zeros((M, D))
+    do_full[::N] = do_row
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(dh)))
+    q64, k64, v64 = (heads_of(qkv.astype(np.float64), B, N, H, dh, i * D) for i in range(3))
+    o, m, l, dq, dk, dv = sdpa_numpy(q64, k64, v64, heads_of(do_full, B, N, H, dh, 0), scale)
+    assert K.dll().vitk_sdpa_row_supported(N, dh) == 1
+    t = dev(qkv)
+    qrow = t[::N, :D].contiguous()  # [B][D]: the query token of every batch entry
+    out, stats = empty(B, D), empty(B * H, 2)
+    K.call("vitk_sdpa_row_fwd", qrow, D, t[:, D:], t[:, 2 * D:], ld, B, H, N, dh, scale, out, D, stats, K.stream())
+    close(host(out).reshape(B, H, dh), o[:, :, 0], 1e-5)
+    st = host(stats).reshape(B, H, 2)
+    close(st[..., 0], m[:, :, 0], 1e-5, floor=1.0)
+    close(st[..., 1], l[:, :, 0], 1e-5)
+    mode = K.DK_REFERENCE if dk_mode == "reference" else K.DK_EXACT
+    grads, dqrow = torch.zeros(M, ld, device="cuda"), empty(B, D)
+    K.call("vitk_sdpa_row_bwd", qrow, D, t[:, D:], t[:, 2 * D:], ld, out, dev(do_row), D, stats, B, H, N, dh, scale, mode,
+           dqrow, D, grads[:, D:], grads[:, 2 * D:], ld, K.stream())
+    g = host(grads)
+    close(host(dqrow).reshape(B, H, dh), dq[:, :, 0], 1e-5)
+    assert np.abs(dq[:, :, 1:]).max() == 0 if N > 1 else True  # the other query rows get no gradient
+    close(heads_of(g, B, N, H, dh, 2 * D), dv, 1e-5)
+    want_dk = dk if dk_mode == "exact" else dk.transpose(0, 1, 3, 2).reshape(B, H, N, dh)
+    close(heads_of(g, B, N, H, dh, D), want_dk, 1e-5)
+    assert not g[:, :D].any() and not g[:, 3 * D:].any()
+
+
 def test_sdpa_rejects_unsupported_shapes(K):
     assert K.dll().vitk_sdpa_supported(257, 64) == 0 and K.dll().vitk_sdpa_supported(197, 65) == 0
     x = empty(4, 4)

@@ -179,6 +179,53 @@ def test_model_activations_gradients_and_steps_match_reference(H, name, fused):
     V.check_digest(m.get_params(), shapes, g["p_sums"], g["p_norms"], g["p_samples"], 5e-5, "param after Adam")
 
 
+@pytest.mark.parametrize("name,B", [("C1", 16), ("C2", 8), ("C3", 2)])
+def test_first_token_tail_equals_the_dense_computation(H, name, B):
+    """The last encoder block and the final norm restricted to the CLS token (the default) against
+    the same model with every token computed: logits (training and inference), loss, every
+    parameter gradient, and the parameters after two Adam steps."""
+    cfgd = V.CONFIGS[name]
+    ocfg = V.Cfg.make(**cfgd)
+    prm = V.init_params(ocfg, 33)
+    K = ocfg.num_classes
+    xs = [dev(V.rng_normal(34 + s, B, ocfg.in_channels, ocfg.image_size, ocfg.image_size)) for s in range(2)]
+    ys = [dev(V.onehot(np.random.default_rng(36 + s).integers(0, K, B), K)) for s in range(2)]
+    runs = {}
+    for tail in (True, False):
+        H.set_first_token_tail(tail)
+        try:
+            m = H.Model(hcfg(H, cfgd))
+            m.set_params(prm)
+            t = H.Trainer(m, weight_decay=1e-4)
+            ev = host_np(m.forward(xs[0], training=False))
+            tr = host_np(m.forward(xs[0], training=True))
+            t.step_forward(xs[0], ys[0])
+            for s in range(t.num_stages):
+                t.backward_stage(s)
+            loss, ok = t.result()
+            g = m.get_grads()
+            for s in range(2):
+                t.train_step(xs[s], ys[s], 1e-3)
+            runs[tail] = (ev, tr, loss, ok, g, m.get_params())
+        finally:
+            H.set_first_token_tail(True)
+    a, b = runs[True], runs[False]
+    close(a[0], b[0], 2e-5, "inference logits")
+    close(a[1], b[1], 2e-5, "training logits")
+    assert abs(a[2] - b[2]) <= 1e-5 * abs(b[2]) and a[3] == b[3]
+    off = 0
+    for i, shp in enumerate(V.param_shapes(ocfg)):
+        k = int(np.prod(shp))
+        close(a[4][off:off + k], b[4][off:off + k], 5e-5, f"grad tensor {i} {shp}", floor=1e-7)
+        # (parameters: Adam divides by the gradient's own magnitude, which amplifies rounding-level
+        # differences of small gradients -- see test_dropout_device_stream_masks_against_the_oracle)
+        assert V.relerr(a[5][off:off + k], b[5][off:off + k]) <= 1e-4, (i, shp)
+        well = np.abs(b[4][off:off + k]) >= 1e-5  # Adam's g / (|g| + 1e-8) is ill-conditioned below
+        if well.any():
+            assert np.abs(a[5][off:off + k] - b[5][off:off + k])[well].max() <= 0.1 * 2e-3, (i, shp)
+        off += k
+
+
 def test_stage_gradient_ranges_tile_the_arena(H):
     cfg = hcfg(H, V.CONFIGS["C1"])
     m = H.Model(cfg)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vith_dropout_state": (_int, [_pu, _pu]),
     "vith_set_dropout_state": (_int, [_u64, _u64]),
     "vith_dropout_replay": (_int, [_p, _u64]),
+    "vith_set_first_token_tail": (_int, [_int]),
     "vith_device_bytes_in_use": (_u64, []),
     "vith_model_create": (_p, [C.POINTER(Config), _int, _int]),
     "vith_model_destroy": (None, [_p]),
@@ -155,6 +156,11 @@ def use_torch_stream():
 def set_fused_attention(on):
     """Attention path of models / layers created afterwards (see include/vit_host.h)."""
     _check(dll().vith_set_fused_attention(int(bool(on))))
+
+
+def set_first_token_tail(on):
+    """Last block + final norm on the CLS token only (default on; see include/vit_host.h)."""
+    _check(dll().vith_set_first_token_tail(int(bool(on))))
 
 
 def seed(s):

@@ -25,6 +25,14 @@ public:
   std::string getName() const override { return "MultiHeadAttention"; }
 
   Tensor forwardFused(const Tensor &input, bool isTraining, const Tensor *residual);
+  // Attention whose output is wanted for the FIRST token only (the last encoder block: only its
+  // CLS token reaches the classification head, src/model/VisionTransformer.cpp:27-37).  Keys and
+  // values are projected for all tokens, the query, the attention core and the output projection
+  // for that one token: input {B,N,D} -> {B,1,D} (+ residual {B,1,D}).  backwardFirstToken takes the
+  // gradient of that output and returns the dense {B,N,D} input gradient.
+  bool firstTokenSupported(size_t tokens) const;
+  Tensor forwardFirstToken(const Tensor &input, bool isTraining, const Tensor *residual);
+  Tensor backwardFirstToken(const Tensor &outputGradient);
   // VITK_DK_REFERENCE (default) reproduces the reference's key-gradient layout; VITK_DK_EXACT is
   // the mathematically correct gradient.  Process-wide default for newly built layers.
   static void setDefaultKeyGradMode(int mode);
@@ -43,6 +51,7 @@ private:
   Tensor wqkv, bqkv, dwqkv, dbqkv;       // packed {D,3D} / {1,3D}
   std::unique_ptr<Dense> q_proj, k_proj, v_proj, out_proj;
   Tensor inputTensor, qkv, attention_weights, softmax_stats, context;
+  Tensor firstInput, firstQuery;  // first-token form: {B,D} input rows and their query projection
 };
 
 #endif  // MULTIHEADATTENTION_HPP

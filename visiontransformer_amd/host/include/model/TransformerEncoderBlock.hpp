@@ -26,6 +26,16 @@ public:
   std::vector<Tensor *> getGradients() override;
   std::string getName() const override { return "TransformerEncoderBlock"; }
   MultiHeadAttention &getAttention() { return attention; }
+  // The block when only the FIRST token of its output is consumed (the last block of the model:
+  // final norm -> CLS slice -> head, src/model/VisionTransformer.cpp:27-37).  Every per-token
+  // stage after the attention core -- output projection, residuals, second norm, feed-forward --
+  // then runs on one row per sequence, and so does the backward up to the attention core, whose
+  // incoming gradient is zero for all other tokens anyway (src/model/VisionTransformer.cpp:49-56).
+  // The values produced for that token, and all parameter gradients, are those of forward() /
+  // backward().  input {B,N,D} -> {B,1,D}; backwardFirstToken({B,1,D}) -> dense {B,N,D}.
+  bool firstTokenSupported(size_t tokens, bool isTraining) const;
+  Tensor forwardFirstToken(const Tensor &input, bool isTraining);
+  Tensor backwardFirstToken(const Tensor &outputGradient);
 
 private:
   LayerNorm norm1;

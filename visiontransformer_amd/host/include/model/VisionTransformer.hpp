@@ -85,6 +85,13 @@ public:
   // backward() returns the image gradient {B,C,H,W} (src/model/VisionTransformer.cpp:68); the staged
   // form used by training steps skips it unless asked.  setDiscardInputGradient(true) lets a
   // caller of backward() that drops the result (Trainer, src/model/Trainer.cpp:212) skip it too.
+  // Process-wide switch (default on): let the last encoder block and the final norm work on the CLS
+  // token only -- the only token the classification head reads (src/model/VisionTransformer.cpp:
+  // 27-37) and the only one whose gradient is non-zero (:49-56).  Logits, loss, every parameter
+  // gradient and every update are those of the dense computation (to rounding: other reduction
+  // lengths); what is skipped is arithmetic whose results nothing reads, and products with zeros.
+  static void setFirstTokenTail(bool on);
+  static bool firstTokenTail();
   void setStageInputGradient(bool want) { wantInputGradient = want; }
   void setDiscardInputGradient(bool discard) { discardInputGradient = discard; }
   // [offset, offset+count) of the gradient arena finalised by `stage`
@@ -113,6 +120,7 @@ private:
   Tensor final_norm_output;
   Tensor stageGrad;
   bool trace = false;
+  bool tailForward = false;  // the last training forward used the first-token form of the last block
   bool wantInputGradient = false, discardInputGradient = false;
   std::vector<Tensor> traceActs, traceGrads;
 };

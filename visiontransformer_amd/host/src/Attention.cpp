@@ -112,6 +112,88 @@ Tensor MultiHeadAttention::forwardFused(const Tensor &input, bool isTraining, co
   return out_proj->forwardFused(ctx, isTraining, VITK_ACT_NONE, nullptr, residual);
 }
 
+bool MultiHeadAttention::firstTokenSupported(size_t tokens) const {
+  return use_fused && vitk_sdpa_row_supported((int32_t)tokens, (int32_t)head_dim) && embedding_dim % 4 == 0;
+}
+
+Tensor MultiHeadAttention::forwardFirstToken(const Tensor &input, bool isTraining, const Tensor *residual) {
+  const auto &s = input.getShape();
+  if (s.size() != 3 || s[2] != embedding_dim) throw std::runtime_error("MultiHeadAttention::forward espera {B,N,D}.");
+  const int64_t B = (int64_t)s[0], N = (int64_t)s[1], D = (int64_t)embedding_dim, h = (int64_t)num_heads,
+                dh = (int64_t)head_dim, M = B * N;
+  Tensor x = input.dense();
+  // k|v = x W_kv + b_kv for every token: the last two thirds of the packed projection
+  Tensor qkvT = Tensor::deviceEmpty({(size_t)M, (size_t)(3 * D)});
+  GemmOpts okv;
+  okv.bias = bqkv.deviceData() + D;
+  vit::gemm(false, false, M, 2 * D, D, x.deviceData(), D, wqkv.deviceData() + D, 3 * D, qkvT.deviceDataOverwrite() + D,
+            3 * D, okv);
+  // q = x[:,0,:] W_q + b_q for the first token of every sequence
+  Tensor x0 = Tensor::deviceEmpty({(size_t)B, (size_t)D});
+  vit::check(vitk_copy2d_f32(x.deviceData(), N * D, x0.deviceDataOverwrite(), D, B, D, S()), "vitk_copy2d_f32");
+  Tensor q0 = Tensor::deviceEmpty({(size_t)B, (size_t)D});
+  GemmOpts oq;
+  oq.bias = bqkv.deviceData();
+  vit::gemm(false, false, B, D, D, x0.deviceData(), D, wqkv.deviceData(), 3 * D, q0.deviceDataOverwrite(), D, oq);
+  const float *k = qkvT.deviceData() + D, *v = k + D;
+  Tensor ctx = Tensor::deviceEmpty({(size_t)B, 1, (size_t)D});
+  Tensor stats = isTraining ? Tensor::deviceEmpty({(size_t)(B * h), 2}) : Tensor();
+  vit::check(vitk_sdpa_row_fwd(q0.deviceData(), D, k, v, 3 * D, (int32_t)B, (int32_t)h, (int32_t)N, (int32_t)dh,
+                               1.0f / std::sqrt(static_cast<float>(head_dim)), ctx.deviceDataOverwrite(), D,
+                               isTraining ? stats.deviceDataOverwrite() : nullptr, S()),
+             "vitk_sdpa_row_fwd");
+  if (isTraining) {
+    inputTensor = x;
+    qkv = qkvT;
+    attention_weights = Tensor();
+    softmax_stats = stats;
+    context = ctx;
+    firstInput = x0;
+    firstQuery = q0;
+  }
+  return out_proj->forwardFused(ctx, isTraining, VITK_ACT_NONE, nullptr, residual);
+}
+
+Tensor MultiHeadAttention::backwardFirstToken(const Tensor &outputGradient) {
+  if (!firstQuery.defined()) throw std::runtime_error("MultiHeadAttention::backward sin forward de entrenamiento.");
+  const auto &s = inputTensor.getShape();
+  const int64_t B = (int64_t)s[0], N = (int64_t)s[1], D = (int64_t)embedding_dim, h = (int64_t)num_heads,
+                dh = (int64_t)head_dim, M = B * N;
+  Tensor dctx = out_proj->backward(outputGradient);  // {B,1,D}
+  Tensor dqkv = Tensor::deviceEmpty({(size_t)M, (size_t)(3 * D)});  // only the k|v columns are produced
+  Tensor dq0 = Tensor::deviceEmpty({(size_t)B, (size_t)D});
+  const float *k = qkv.deviceData() + D, *v = k + D;
+  float *dk = dqkv.deviceDataOverwrite() + D, *dv = dk + D;
+  vit::check(vitk_sdpa_row_bwd(firstQuery.deviceData(), D, k, v, 3 * D, context.deviceData(), dctx.deviceData(), D,
+                               softmax_stats.deviceData(), (int32_t)B, (int32_t)h, (int32_t)N, (int32_t)dh,
+                               1.0f / std::sqrt(static_cast<float>(head_dim)), dk_mode, dq0.deviceDataOverwrite(), D, dk,
+                               dv, 3 * D, S()),
+             "vitk_sdpa_row_bwd");
+  const float *x = inputTensor.deviceData();
+  {  // dW_kv = X^T dKV over all tokens (+ bias gradients from the same launch)
+    GemmOpts o;
+    o.split_k = 0;
+    o.colsum_b = dbqkv.deviceData() + D;
+    vit::gemm(true, false, D, 2 * D, M, x, D, dk, 3 * D, dwqkv.deviceData() + D, 3 * D, o);
+  }
+  {  // dW_q = X0^T dQ0 over the first tokens
+    GemmOpts o;
+    o.colsum_b = dbqkv.deviceData();
+    vit::gemm(true, false, D, D, B, firstInput.deviceData(), D, dq0.deviceData(), D, dwqkv.deviceData(), 3 * D, o);
+  }
+  // dX = dKV W_kv^T for every token, plus dQ0 W_q^T added into the first token's rows
+  Tensor dx = Tensor::deviceEmpty(inputTensor.getShape());
+  float *dxp = dx.deviceDataOverwrite();
+  vit::gemm(false, true, M, D, 2 * D, dk, 3 * D, wqkv.deviceData() + D, 3 * D, dxp, D);
+  {
+    GemmOpts o;
+    o.residual = dxp;
+    o.ldr = N * D;
+    vit::gemm(false, true, B, D, D, dq0.deviceData(), D, wqkv.deviceData(), 3 * D, dxp, N * D, o);
+  }
+  return dx;
+}
+
 Tensor MultiHeadAttention::backward(const Tensor &outputGradient) {
   if (!inputTensor.defined()) throw std::runtime_error("MultiHeadAttention::backward sin forward de entrenamiento.");
   const auto &s = inputTensor.getShape();

@@ -45,6 +45,38 @@ Tensor TransformerEncoderBlock::backward(const Tensor &outputGradient) {
   return norm1.backwardFused(gm, &grad1);
 }
 
+bool TransformerEncoderBlock::firstTokenSupported(size_t tokens, bool isTraining) const {
+  // (with dropout active the masks are indexed by position in the full {B,N,D} tensors: dense path)
+  return !attention_dropout.active(isTraining) && attention.firstTokenSupported(tokens);
+}
+
+Tensor TransformerEncoderBlock::forwardFirstToken(const Tensor &input, bool isTraining) {
+  const auto &s = input.getShape();
+  const size_t B = s[0], N = s[1], D = s[2];
+  Tensor in = input.dense();
+  Tensor x = norm1.forward(in, isTraining);  // all tokens: keys and values need them
+  Tensor in0 = Tensor::deviceEmpty({B, 1, D});
+  vit::check(vitk_copy2d_f32(in.deviceData(), (int64_t)(N * D), in0.deviceDataOverwrite(), (int64_t)D, (int64_t)B,
+                             (int64_t)D, S()),
+             "vitk_copy2d_f32");
+  Tensor residual1 = attention.forwardFirstToken(x, isTraining, &in0);  // {B,1,D}
+  Tensor y = norm2.forward(residual1, isTraining);
+  return ffn.forwardFused(y, isTraining, &residual1);
+}
+
+Tensor TransformerEncoderBlock::backwardFirstToken(const Tensor &outputGradient) {
+  Tensor g = ffn.backward(outputGradient);                   // {B,1,D}
+  Tensor grad1 = norm2.backwardFused(g, &outputGradient);    // d residual1 of the first token
+  Tensor gm = attention.backwardFirstToken(grad1);           // dense {B,N,D}: keys / values of every token
+  Tensor dx = norm1.backwardFused(gm, nullptr);
+  const auto &s = dx.getShape();
+  // skip connection of the first token: d input[:,0,:] += d residual1
+  vit::check(vitk_add2d_f32(grad1.deviceData(), (int64_t)s[2], dx.deviceData(), (int64_t)(s[1] * s[2]), (int64_t)s[0],
+                            (int64_t)s[2], S()),
+             "vitk_add2d_f32");
+  return dx;
+}
+
 std::vector<Tensor *> TransformerEncoderBlock::getParameters() {
   std::vector<Tensor *> params;
   for (Layer *l : std::initializer_list<Layer *>{&norm1, &attention, &norm2, &ffn}) {
@@ -95,18 +127,34 @@ VisionTransformer::VisionTransformer(const ViTConfig &config)
   if (params->used() != params->size()) throw std::runtime_error("VisionTransformer: arena size mismatch");
 }
 
+namespace {
+bool g_first_token_tail = true;
+}  // namespace
+void VisionTransformer::setFirstTokenTail(bool on) { g_first_token_tail = on; }
+bool VisionTransformer::firstTokenTail() { return g_first_token_tail; }
+
 Tensor VisionTransformer::forward(const Tensor &input, bool isTraining) {
   if (trace) traceActs.clear();
   Tensor x = embeddings.forward(input, isTraining);
   if (trace) traceActs.push_back(x);
-  for (auto &block : encoder_blocks) {
-    x = block.forward(x, isTraining);
+  const size_t L = encoder_blocks.size(), B = input.getShape()[0];
+  // Only the CLS token of the last block's output is read below, so that block (and the final
+  // norm) can work on one row per sequence.  Tracing wants every token of every layer: dense then.
+  const bool tail = g_first_token_tail && !trace && L > 0 && encoder_blocks[L - 1].firstTokenSupported(num_tokens, isTraining);
+  for (size_t i = 0; i + (tail ? 1 : 0) < L; ++i) {
+    x = encoder_blocks[i].forward(x, isTraining);
     if (trace) traceActs.push_back(x);
+  }
+  if (isTraining) tailForward = tail;
+  if (tail) {
+    x = encoder_blocks[L - 1].forwardFirstToken(x, isTraining);  // {B,1,D}
+    x = final_norm.forward(x, isTraining);
+    if (isTraining) final_norm_output = x;
+    return mlp_head.forward(x.reshape({B, config.embedding_dim}), isTraining);
   }
   x = final_norm.forward(x, isTraining);
   if (trace) traceActs.push_back(x);
   if (isTraining) final_norm_output = x;
-  const size_t B = input.getShape()[0];
   Tensor cls = Tensor::deviceEmpty({B, config.embedding_dim});
   vit::check(vitk_cls_gather(x.deviceData(), (int32_t)B, (int32_t)num_tokens, (int32_t)config.embedding_dim,
                              cls.deviceDataOverwrite(), S()),
@@ -121,7 +169,21 @@ void VisionTransformer::backwardBegin(const Tensor &outputGradient) {
 
 void VisionTransformer::backwardStage(size_t stage) {
   const size_t L = encoder_blocks.size();
-  if (stage == 0) {
+  if (stage == 0 && tailForward) {
+    Tensor g = mlp_head.backward(stageGrad);  // {B,D}: the gradient of the CLS rows, all others are zero
+    const size_t B = g.getShape()[0];
+    stageGrad = final_norm.backward(g.reshape({B, 1, config.embedding_dim}));
+    if (trace) {  // traced gradients are dense {B,N,D}: zero except the CLS rows
+      Tensor seq = Tensor::deviceEmpty({B, num_tokens, config.embedding_dim});
+      vit::check(vitk_cls_scatter(stageGrad.deviceData(), (int32_t)B, (int32_t)num_tokens, (int32_t)config.embedding_dim,
+                                  seq.deviceDataOverwrite(), S()),
+                 "vitk_cls_scatter");
+      traceGrads.push_back(seq);
+    }
+    return;
+  } else if (stage == 1 && tailForward) {
+    stageGrad = encoder_blocks[L - 1].backwardFirstToken(stageGrad);
+  } else if (stage == 0) {
     Tensor g = mlp_head.backward(stageGrad);  // {B,D}
     const size_t B = g.getShape()[0];
     // re-inject the CLS gradient into a zero {B,N,D} sequence (src/model/VisionTransformer.cpp:49-56)

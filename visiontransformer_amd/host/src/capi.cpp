@@ -179,6 +179,9 @@ int vith_set_dropout_state(uint64_t seed, uint64_t offset) {
 int vith_dropout_replay(const float *masks_dev, uint64_t count) {
   return guard([&] { vit::set_dropout_replay(masks_dev, (size_t)count); });
 }
+int vith_set_first_token_tail(int on) {
+  return guard([&] { VisionTransformer::setFirstTokenTail(on != 0); });
+}
 uint64_t vith_device_bytes_in_use(void) { return vit::device_bytes_in_use(); }
 
 vith_model vith_model_create(const vith_config *cfg, int patch_mode, int dk_mode) {

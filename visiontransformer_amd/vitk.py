@@ -77,6 +77,11 @@ SIGNATURES = {
     "vitk_sdpa_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "vitk_sdpa_bwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _i32, _i32, _i32, _i32, _f, _i32, _p, _p, _p, _i64,
                                 _p, _sz, _p]),
+    "vitk_sdpa_row_supported": (C.c_int, [_i32, _i32]),
+    "vitk_sdpa_row_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _i64, _p, _p]),
+    "vitk_sdpa_row_bwd": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i32, _i32, _i32, _i32, _f, _i32, _p, _i64,
+                                    _p, _p, _i64, _p]),
+    "vitk_add2d_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "vitk_patch_gather": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "vitk_patch_scatter_bwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "vitk_embed_assemble": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
