@@ -100,7 +100,7 @@ def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC profile of this same command
     (rocprofv3 cannot collect counters from inside a timed run); None if there is no profile."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
             return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -228,7 +228,7 @@ def main():
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": measured_traffic(dom["name"]),
                          "traffic_note": "HBM bytes per launch, rocprofv3 PMC passes of this command "
-                                         "(profiles/r01_hbm_traffic.json)",
+                                         "(profiles/r02_hbm_traffic.json)",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                          "flops_per_launch": dom["flops"] / dom["launches"],
                          "all_gemm_ms_per_step": round(gemm_ms / args.steps, 3),
