@@ -95,13 +95,22 @@ int vitk_gemm_f32(const vitk_gemm_args *args, vitk_stream_t stream);
 size_t vitk_gemm_workspace_bytes(const vitk_gemm_args *args);
 
 /* Measurement aid for bench.py (not used by the training path): while enabled, every main
- * contraction launch is bracketed by two HIP events on its stream.  variant = 8*full +
- * 4*(tile==64) + 2*trans_a + trans_b (0..15) identifies the kernel instantiation (vitk_gemm_variant_name gives the name a
+ * contraction launch is bracketed by two HIP events on its stream.  variant = 16*colsum + 8*full +
+ * 4*(tile==64) + 2*trans_a + trans_b (0..31) identifies the instantiation of the tiled kernel and
+ * 32 + 2*trans_a + trans_b the small-problem kernel (vitk_gemm_variant_name gives the name a
  * profiler shows); vitk_gemm_profile_read returns the summed event time, the summed algorithmic
  * FLOPs (2*M*N*K*batch) and the launch count of one variant, optionally clearing all records. */
 int vitk_gemm_profile_enable(int on);
 int vitk_gemm_profile_read(int variant, double *total_ms, double *total_flops, int64_t *launches, int reset);
 const char *vitk_gemm_variant_name(int variant);
+
+/* Problems of at most 8 x (compute units) 16 x 16 output tiles with K <= 1024, no batch and no
+ * forced split run on a kernel of their own (one wave per tile, operands straight from global
+ * memory: on a nearly idle chip the tiled kernel's slab pipeline is pure latency).  Same
+ * arguments, epilogue and colsum_b; the summation order over k differs, so results agree with the
+ * tiled kernel to rounding, not bitwise.  on = 0 keeps everything on the tiled kernel (tests,
+ * measurements); the default is on.  Process-wide. */
+int vitk_gemm_small_enable(int on);
 
 /* ---- column sum: out[j] = sum_i x[i][j]  (Tensor::sum(0), src/core/Tensor.cpp:385-430; the
  * bias gradient of Dense::backward, src/layers/Dense.cpp:95, and dpos/dcls of

@@ -25,6 +25,22 @@ def K():
     return vitk
 
 
+@pytest.fixture
+def gemm_path(request, K):
+    """Every test_gemm_* runs twice: with small problems routed to the one-wave-per-tile kernel (the
+    default) and with everything kept on the tiled kernel."""
+    K.gemm_small(request.param == "small_kernel_on")
+    yield request.param
+    K.gemm_small(True)
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__.startswith("test_gemm_"):
+        if "gemm_path" not in metafunc.fixturenames:
+            metafunc.fixturenames.append("gemm_path")
+        metafunc.parametrize("gemm_path", ["small_kernel_on", "tiled_only"], indirect=True)
+
+
 def dev(a):
     a = np.ascontiguousarray(a)
     assert a.dtype in (np.float32, np.int32), a.dtype

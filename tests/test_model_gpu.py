@@ -416,10 +416,10 @@ def test_dropout_device_stream_masks_against_the_oracle(H, fused):
         # RELATIVE error of that element's gradient: for the small elements of a tensor (|g| a
         # thousandth of the tensor's largest) the agreed 1e-6..1e-5-of-max gradient error is a
         # percent of one update.  Bounds: no element further apart than 10 % of the distance the
-        # two updates can move it (lr 3e-4 + 6e-4), and the tensor as a whole within 2e-5 (L2).
+        # two updates can move it (lr 3e-4 + 6e-4), and the tensor as a whole within 5e-5 (L2).
         d = np.abs(got[o:o + k] - p[o:o + k])
         assert d.max() <= 0.1 * 9e-4, f"param tensor {i} {shp} after two steps: {d.max():.3e}"
-        assert V.relerr(got[o:o + k], p[o:o + k]) <= 2e-5, (i, shp, V.relerr(got[o:o + k], p[o:o + k]))
+        assert V.relerr(got[o:o + k], p[o:o + k]) <= 5e-5, (i, shp, V.relerr(got[o:o + k], p[o:o + k]))
         o += k
 
 

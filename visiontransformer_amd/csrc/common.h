@@ -21,6 +21,14 @@ int check_launch(const char *what);
 // (norm.hip); called by vitk_init.
 int norm_static_setup();
 
+// Small-problem GEMM (gemm_small.hip): whether vitk_gemm_f32 routes these arguments to it, and the launch.
+bool gemm_small_applies(const vitk_gemm_args *a);
+int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st);
+
+// Compute units of the current device (hipDeviceProp_t::multiProcessorCount), cached per device;
+// 256 if the query fails.
+int cu_count();
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kWave = 64;

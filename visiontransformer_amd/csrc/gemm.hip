@@ -654,11 +654,11 @@ struct Plan {
 
 int choose_split(long long tiles, int K) {
   // Weight-gradient GEMMs contract over all B*N token rows into a small [in][out] matrix: too few
-  // output tiles to occupy 256 CUs.  Split the contraction so that tiles*splits comes just under
-  // one full round of resident workgroups (256 CUs x kBlocksPerCU): every workgroup then runs
+  // output tiles to occupy the chip's CUs (256 on MI355X).  Split the contraction so that tiles*splits comes just under
+  // one full round of resident workgroups (CUs x kBlocksPerCU): every workgroup then runs
   // concurrently and they all finish together -- a second, mostly empty round would cost as much
   // as the first.
-  const long long slots = 256 * kBlocksPerCU;
+  const long long slots = (long long)vitk::cu_count() * kBlocksPerCU;
   if (tiles >= slots / 2) return 1;
   long long want = slots / tiles;
   long long max_by_k = K / (8 * BK);
@@ -698,13 +698,13 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
   // reads per FLOP).  Take whichever the fill predicts to be faster (measured on the ViT-B shapes
   // at batch 8..64: within a few percent of the better choice everywhere, up to +50 %).
   if (pl->tile == 128 && s == 1 && a->reserved != 1) {
-    const long long slots = 256 * kBlocksPerCU;
+    const long long cus = vitk::cu_count(), slots = cus * kBlocksPerCU;
     const long long t128 = (long long)pl->tiles_m * pl->tiles_n * pl->batch;
     const long long t64 = (long long)((a->M + 63) / 64) * ((a->N + 63) / 64) * pl->batch;
-    auto fill = [](long long n) { return (double)n / (256.0 * (double)((n + 255) / 256)); };
+    auto fill = [cus](long long n) { return (double)n / ((double)cus * (double)((n + cus - 1) / cus)); };
     // a small remainder after whole rounds is cut off and run on 64-wide tiles anyway (tail round)
     double e128 = (t128 >= slots && t128 % slots <= 128) ? 0.98 : fill(t128);
-    if (t128 < 512) e128 *= 0.9;  // fewer than two workgroups per CU: latencies show
+    if (t128 < 2 * cus) e128 *= 0.9;  // fewer than two workgroups per CU: latencies show
     const double e64 = fill(t64) * 0.94;
     if (e64 > e128) {
       pl->tile = 64;
@@ -787,19 +787,38 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   VITK_REQUIRE(a->aux == nullptr || a->ldaux >= a->N, "vitk_gemm_f32: ldaux %lld < N", (long long)a->ldaux);
   VITK_REQUIRE(a->residual == nullptr || a->ldr >= a->N, "vitk_gemm_f32: ldr %lld < N", (long long)a->ldr);
 
+  if (vitk::gemm_small_applies(a)) {  // too small to fill the chip: one wave per 16 x 16 tile (gemm_small.hip)
+    VITK_REQUIRE(a->colsum_b == nullptr || a->trans_b == 0, "vitk_gemm_f32: colsum_b needs trans_b == 0 and batch == 1");
+    hipStream_t st = vitk::as_stream(stream);
+    ProfRec rec{};
+    if (g_prof_on) {
+      rec.variant = 32 + (a->trans_a ? 2 : 0) + (a->trans_b ? 1 : 0);
+      rec.flops = 2.0 * a->M * a->N * a->K;
+      rec.e0 = prof_event();
+      rec.e1 = prof_event();
+      (void)hipEventRecord(rec.e0, st);
+    }
+    const int rc = vitk::gemm_small_launch(a, st);
+    if (g_prof_on) {
+      (void)hipEventRecord(rec.e1, st);
+      g_prof.push_back(rec);
+    }
+    return rc;
+  }
+
   Plan pl;
   make_plan(a, &pl);
   const bool plain = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
   VITK_REQUIRE(pl.split_k == 1 || plain, "vitk_gemm_f32: split-K needs alpha == 1 and no bias/act/residual");
 
-  // Tail round.  The chip holds 256 x kBlocksPerCU workgroups; when the tile count leaves a small
+  // Tail round.  The chip holds CUs x kBlocksPerCU workgroups; when the tile count leaves a small
   // remainder after the last full round (N = 768: 394 x 6 tiles = 3 rounds + 60), those few 128-wide
   // tiles would each run alone on a CU while most CUs idle.  Cut the trailing tile rows off and run
   // them as a second launch, which make_plan covers with four times as many 64-wide tiles.
   if (a->reserved == 0 && pl.tile == 128 && pl.split_k == 1 && pl.batch == 1 &&
       a->colsum_b == nullptr) {
-    const int slots = 256 * kBlocksPerCU;
-    constexpr int tail_max = 128;  // larger remainders already spread over most CUs (measured: no gain)
+    const int slots = vitk::cu_count() * kBlocksPerCU;
+    const int tail_max = vitk::cu_count() / 2;  // larger remainders already spread over most CUs (measured: no gain)
     const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
     const int head_rows = (int)(tiles / slots * slots / pl.tiles_n);  // tile rows inside the full rounds
     const int tail_rows = pl.tiles_m - head_rows;
@@ -900,7 +919,7 @@ extern "C" int vitk_gemm_profile_enable(int on) {
 
 extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *total_flops, int64_t *launches,
                                       int reset) {
-  VITK_REQUIRE(variant >= 0 && variant < 32, "vitk_gemm_profile_read: variant %d outside [0,32)", variant);
+  VITK_REQUIRE(variant >= 0 && variant < 36, "vitk_gemm_profile_read: variant %d outside [0,36)", variant);
   double ms = 0.0, fl = 0.0;
   int64_t n = 0;
   for (const ProfRec &r : g_prof) {
@@ -929,8 +948,13 @@ extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *tot
 
 extern "C" const char *vitk_gemm_variant_name(int variant) {
   // the names a profiler prints: gemm_kernel<TILE, TA, TB, FULL, CS>
-  static char names[32][48];
-  if (variant < 0 || variant >= 32) return "";
+  static char names[36][48];
+  if (variant < 0 || variant >= 36) return "";
+  if (variant >= 32) {  // gemm_small_kernel<AV, BV>: the template flags depend on alignment; name the transposes
+    std::snprintf(names[variant], sizeof names[variant], "gemm_small_kernel (%s)",
+                  variant == 32 ? "NN" : variant == 33 ? "NT" : variant == 34 ? "TN" : "TT");
+    return names[variant];
+  }
   const bool cs = variant & 16, full = variant & 8, t64 = variant & 4, ta = variant & 2, tb = variant & 1;
   std::snprintf(names[variant], sizeof names[variant], "gemm_kernel<%d, %s, %s, %s, %s>", t64 ? 64 : 128,
                 ta ? "true" : "false", tb ? "true" : "false", full ? "true" : "false", cs ? "true" : "false");

@@ -1,0 +1,189 @@
+// fp32 GEMM for problems too small to occupy the chip: one wave per 16 x 16 output tile.
+//
+// The tiled kernel of gemm.hip is built for throughput: a workgroup walks the contraction in
+// 16-deep slabs through an LDS ring, and with a handful of workgroups on an otherwise idle chip
+// every slab costs a full global-memory round trip (measured: 8 us at K = 96, 15 us at K = 384 for
+// a 320-row problem whose arithmetic is worth well under a microsecond).  The small models of the
+// reference (vit_mnist_4_8: 5 tokens, 96 features) consist of nothing but such contractions.
+// Here nothing is staged or shared: each wave reads its 16 rows of A and 16 columns of B straight
+// from global memory (they come from L2 after the first touch) in the operand layout of
+// v_mfma_f32_16x16x4_f32, four k-chunks of loads in flight ahead of the multiplies, and the whole
+// problem is spread over as many SIMDs as it has 16 x 16 tiles.  Same epilogue and the same
+// column-sum side output as vitk_gemm_f32.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SmallParams {
+  int M, N, K;
+  const float *A;  // element (m, k) at A[m * sam + k * sak]
+  long long sam, sak;
+  const float *B;  // element (k, n) at B[k * sbk + n * sbn]
+  long long sbk, sbn;
+  float *C;
+  long long ldc;
+  float alpha;
+  int act;
+  const float *bias;
+  const float *residual;
+  long long ldr;
+  float *aux;
+  long long ldaux;
+  float *colsum;
+  int tiles_n;
+};
+
+constexpr int U = 4;  // k-chunks (of 16) per batch of loads
+
+// Four consecutive k (k0 .. k0+3) of one row of A or one column of B; `base` points at k = 0 of it.
+// VEC: k is contiguous in memory and the 16 bytes are aligned.  TAIL: k may run past K -- the
+// address is clamped into the operand and the value replaced by zero, so the loads stay
+// unconditional (a batch of them issues back to back, with no branch in between).
+template <bool VEC, bool TAIL>
+__device__ __forceinline__ f32x4 load4(const float *__restrict__ base, long long sk, int k0, int K) {
+  f32x4 v;
+  if constexpr (VEC) {  // K % 4 == 0 and k0 % 4 == 0: a quad is inside or outside as a whole
+    const int kc = TAIL ? min(k0, K - 4) : k0;
+    v = *reinterpret_cast<const f32x4 *>(base + kc);
+    if (TAIL && k0 >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    const float *__restrict__ q = base + (long long)(TAIL ? min(k0, K - 1) : k0) * sk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (TAIL) {
+        const float x = base[(long long)min(k0 + e, K - 1) * sk];
+        v[e] = k0 + e < K ? x : 0.f;
+      } else {
+        v[e] = q[e * sk];
+      }
+    }
+  }
+  return v;
+}
+
+template <bool AV, bool BV>
+__global__ __launch_bounds__(64) void gemm_small_kernel(const SmallParams p) {
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  // lane (c, g) feeds row m of A and column n of B at k = 16*chunk + 4*g + e into step e of the
+  // chunk: v_mfma_f32_16x16x4_f32 takes A[i = lane % 16][k = lane / 16] and B[k = lane / 16][j = lane % 16].
+  // Rows and columns beyond the matrix read the last valid one instead: row i of A only reaches
+  // row i of the product and column j of B only column j, and those are never stored.
+  const int m = tm * 16 + c, n = tn * 16 + c;
+  const bool n_ok = n < p.N;
+  const float *__restrict__ ap = p.A + (long long)min(m, p.M - 1) * p.sam;
+  const float *__restrict__ bp = p.B + (long long)min(n, p.N - 1) * p.sbn;
+  const bool do_colsum = p.colsum != nullptr && tm == 0;
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, csum = acc0;
+  f32x4 a0[U], b0[U], a1[U], b1[U];
+  const int nfull = p.K / (16 * U);                     // batches with every k inside the contraction
+  const int nbatch = (p.K + 16 * U - 1) / (16 * U);     // nfull, or one more (ragged)
+
+#define VITK_LOAD(BATCH, RA, RB)                                              \
+  if ((BATCH) < nfull) {                                                      \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                           \
+      const int k0 = ((BATCH)*U + u) * 16 + 4 * g;                            \
+      RA[u] = load4<AV, false>(ap, p.sak, k0, p.K);                           \
+      RB[u] = load4<BV, false>(bp, p.sbk, k0, p.K);                           \
+    }                                                                         \
+  } else {                                                                    \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                           \
+      const int k0 = ((BATCH)*U + u) * 16 + 4 * g;                            \
+      RA[u] = load4<AV, true>(ap, p.sak, k0, p.K);                            \
+      RB[u] = load4<BV, true>(bp, p.sbk, k0, p.K);                            \
+    }                                                                         \
+  }
+  // two accumulators (even / odd chunks): a chain of dependent 16x16x4 MFMAs issues every 40
+  // cycles, two interleaved chains every 32
+#define VITK_MULTIPLY(RA, RB)                                                               \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
+      if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(RA[u][e], RB[u][e], acc1, 0, 0, 0); \
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(RA[u][e], RB[u][e], acc0, 0, 0, 0);  \
+    }                                                                                       \
+    csum += RB[u];                                                                          \
+  }
+
+  VITK_LOAD(0, a0, b0)
+  for (int bt = 0; bt < nbatch; bt += 2) {
+    if (bt + 1 < nbatch) { VITK_LOAD(bt + 1, a1, b1) }
+    VITK_MULTIPLY(a0, b0)
+    if (bt + 2 < nbatch) { VITK_LOAD(bt + 2, a0, b0) }
+    if (bt + 1 < nbatch) { VITK_MULTIPLY(a1, b1) }
+  }
+#undef VITK_LOAD
+#undef VITK_MULTIPLY
+
+  if (do_colsum) {  // wave-uniform
+    // this lane added B[k][n] over its k (4g + e of every chunk); the other three k-groups of the
+    // column sit 16, 32 and 48 lanes away.  Fixed order.
+    float t = (csum[0] + csum[1]) + (csum[2] + csum[3]);
+    t += __shfl_xor(t, 16);
+    t += __shfl_xor(t, 32);
+    if (g == 0 && n_ok) p.colsum[n] = t;
+  }
+
+  // accumulator register r of lane (c, g) is C[4g + r][c] of the tile
+  if (!n_ok) return;
+  const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = tm * 16 + 4 * g + r;
+    if (row >= p.M) continue;
+    float v = p.alpha * (acc0[r] + acc1[r]);
+    if (p.act == VITK_ACT_GELU_BWD) v *= vitk::gelu_grad(p.aux[(long long)row * p.ldaux + n]);
+    v += bv;
+    if (p.act == VITK_ACT_GELU_FWD) {
+      if (p.aux != nullptr) p.aux[(long long)row * p.ldaux + n] = v;
+      v = vitk::gelu_fwd(v);
+    }
+    if (p.residual != nullptr) v += p.residual[(long long)row * p.ldr + n];
+    p.C[(long long)row * p.ldc + n] = v;
+  }
+}
+
+bool g_small_on = true;
+
+}  // namespace
+
+namespace vitk {
+
+// Whether vitk_gemm_f32 hands these arguments to the small-problem kernel: one contraction (no
+// batch, no forced split), short enough that a single wave's chain of MFMAs stays in the
+// microseconds, and few enough tiles that every wave gets a SIMD of its own (or nearly).
+bool gemm_small_applies(const vitk_gemm_args *a) {
+  if (!g_small_on || a->reserved != 0 || a->split_k > 1) return false;
+  if ((a->batch_outer > 1) || (a->batch_inner > 1)) return false;
+  if (a->K < 1 || a->K > 1024) return false;
+  const long long tiles = (long long)((a->M + 15) / 16) * ((a->N + 15) / 16);
+  return tiles <= 8LL * cu_count();
+}
+
+int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st) {
+  SmallParams p;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.A = a->A; p.sam = a->trans_a ? 1 : a->lda; p.sak = a->trans_a ? a->lda : 1;
+  p.B = a->B; p.sbk = a->trans_b ? 1 : a->ldb; p.sbn = a->trans_b ? a->ldb : 1;
+  p.C = a->C; p.ldc = a->ldc; p.alpha = a->alpha; p.act = a->act; p.bias = a->bias;
+  p.residual = a->residual; p.ldr = a->ldr; p.aux = a->aux; p.ldaux = a->ldaux;
+  p.colsum = a->colsum_b;
+  p.tiles_n = (a->N + 15) / 16;
+  const bool av = !a->trans_a && a->lda % 4 == 0 && a->K % 4 == 0 && aligned16(a->A);
+  const bool bv = a->trans_b && a->ldb % 4 == 0 && a->K % 4 == 0 && aligned16(a->B);
+  const dim3 grid((unsigned)(((a->M + 15) / 16) * p.tiles_n)), blk(64);
+  if (av && bv) hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, blk, 0, st, p);
+  else if (av) hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, blk, 0, st, p);
+  else if (bv) hipLaunchKernelGGL((gemm_small_kernel<false, true>), grid, blk, 0, st, p);
+  else hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, blk, 0, st, p);
+  return check_launch("vitk_gemm_f32/small");
+}
+
+}  // namespace vitk
+
+extern "C" int vitk_gemm_small_enable(int on) {
+  g_small_on = on != 0;
+  return 0;
+}

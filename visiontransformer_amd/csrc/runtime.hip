@@ -23,6 +23,18 @@ int check_launch(const char *what) {
   return 0;
 }
 
+int cu_count() {
+  static int cached[64] = {0};  // benign race: every thread writes the same value
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 }  // namespace vitk
 
 extern "C" {

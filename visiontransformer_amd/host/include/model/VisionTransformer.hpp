@@ -121,6 +121,7 @@ private:
   Tensor stageGrad;
   bool trace = false;
   bool tailForward = false;  // the last training forward used the first-token form of the last block
+  bool normFirstOnly = false;  // ... or the dense last block with the final norm on the CLS rows only
   bool wantInputGradient = false, discardInputGradient = false;
   std::vector<Tensor> traceActs, traceGrads;
 };

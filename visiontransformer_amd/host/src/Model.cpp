@@ -152,8 +152,20 @@ Tensor VisionTransformer::forward(const Tensor &input, bool isTraining) {
     if (isTraining) final_norm_output = x;
     return mlp_head.forward(x.reshape({B, config.embedding_dim}), isTraining);
   }
+  if (isTraining) normFirstOnly = !trace;
+  if (!trace) {
+    // The head reads the CLS row of the normalised sequence and LayerNorm works row by row: pick
+    // the row first and normalise B rows instead of B*N (src/model/VisionTransformer.cpp:34-40).
+    Tensor cls = Tensor::deviceEmpty({B, 1, config.embedding_dim});
+    vit::check(vitk_cls_gather(x.deviceData(), (int32_t)B, (int32_t)num_tokens, (int32_t)config.embedding_dim,
+                               cls.deviceDataOverwrite(), S()),
+               "vitk_cls_gather");
+    cls = final_norm.forward(cls, isTraining);
+    if (isTraining) final_norm_output = cls;
+    return mlp_head.forward(cls.reshape({B, config.embedding_dim}), isTraining);
+  }
   x = final_norm.forward(x, isTraining);
-  if (trace) traceActs.push_back(x);
+  traceActs.push_back(x);
   if (isTraining) final_norm_output = x;
   Tensor cls = Tensor::deviceEmpty({B, config.embedding_dim});
   vit::check(vitk_cls_gather(x.deviceData(), (int32_t)B, (int32_t)num_tokens, (int32_t)config.embedding_dim,
@@ -188,10 +200,18 @@ void VisionTransformer::backwardStage(size_t stage) {
     const size_t B = g.getShape()[0];
     // re-inject the CLS gradient into a zero {B,N,D} sequence (src/model/VisionTransformer.cpp:49-56)
     Tensor seq = Tensor::deviceEmpty({B, num_tokens, config.embedding_dim});
-    vit::check(vitk_cls_scatter(g.deviceData(), (int32_t)B, (int32_t)num_tokens, (int32_t)config.embedding_dim,
-                                seq.deviceDataOverwrite(), S()),
-               "vitk_cls_scatter");
-    stageGrad = final_norm.backward(seq);
+    if (normFirstOnly) {  // rows with a zero gradient add exactly nothing to dgamma / dbeta and get dx = 0
+      g = final_norm.backward(g.reshape({B, 1, config.embedding_dim}));
+      vit::check(vitk_cls_scatter(g.deviceData(), (int32_t)B, (int32_t)num_tokens, (int32_t)config.embedding_dim,
+                                  seq.deviceDataOverwrite(), S()),
+                 "vitk_cls_scatter");
+      stageGrad = seq;
+    } else {
+      vit::check(vitk_cls_scatter(g.deviceData(), (int32_t)B, (int32_t)num_tokens, (int32_t)config.embedding_dim,
+                                  seq.deviceDataOverwrite(), S()),
+                 "vitk_cls_scatter");
+      stageGrad = final_norm.backward(seq);
+    }
   } else if (stage <= L) {
     stageGrad = encoder_blocks[L - stage].backward(stageGrad);
   } else if (stage == L + 1) {

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vitk_gemm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_int64), C.c_int]),
     "vitk_gemm_variant_name": (C.c_char_p, [C.c_int]),
+    "vitk_gemm_small_enable": (C.c_int, [C.c_int]),
     "vitk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "vitk_colsum_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "vitk_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
@@ -173,6 +174,11 @@ def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=Non
     return keep
 
 
+def gemm_small(enable):
+    """Route small problems to the one-wave-per-tile kernel (the default) or keep them on the tiled one."""
+    check(dll().vitk_gemm_small_enable(int(enable)))
+
+
 def gemm_profile(enable):
     check(dll().vitk_gemm_profile_enable(int(enable)))
 
@@ -180,7 +186,7 @@ def gemm_profile(enable):
 def gemm_profile_read(reset=True):
     """Per kernel variant: dict(name, ms, flops, launches) for variants that were launched."""
     out = []
-    for v in range(32):
+    for v in range(36):
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         check(dll().vitk_gemm_profile_read(v, C.byref(ms), C.byref(fl), C.byref(n), 0))
         if n.value:
