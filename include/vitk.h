@@ -224,6 +224,11 @@ int vitk_dk_reference_scatter(const float *t, int32_t B, int32_t heads, int32_t 
  * (vitk_sdpa_supported); callers fall back to vitk_gemm_f32 + vitk_softmax_rows otherwise.
  * workspace: vitk_sdpa_bwd_workspace_bytes(B, H, N) bytes. */
 int vitk_sdpa_supported(int32_t N, int32_t dh);
+/* Head dimensions 33..64 with 16-byte-aligned operands run the forward on 16-row tiles with four
+ * heads per workgroup (197 tokens = 13 tiles instead of 7 x 32 = 224 rows, every wave busy in
+ * every round).  on = 0 keeps them on the 32-row kernel that serves the other head sizes (tests,
+ * measurements); the default is on.  Same results to rounding.  Process-wide. */
+int vitk_sdpa_tile16_enable(int on);
 int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv, int32_t B, int32_t H, int32_t N,
                   int32_t dh, float scale, float *out, int64_t ld_out, float *stats, vitk_stream_t stream);
 size_t vitk_sdpa_bwd_workspace_bytes(int32_t B, int32_t H, int32_t N);

@@ -34,11 +34,25 @@ def gemm_path(request, K):
     K.gemm_small(True)
 
 
+@pytest.fixture
+def sdpa_path(request, K):
+    """Every test_sdpa_* runs twice: head dimensions 33..64 on the 16-row-tile forward (the default)
+    and on the 32-row-tile forward that serves the other head sizes."""
+    K.sdpa_tile16(request.param == "tile16_on")
+    yield request.param
+    K.sdpa_tile16(True)
+
+
 def pytest_generate_tests(metafunc):
-    if metafunc.function.__name__.startswith("test_gemm_"):
+    name = metafunc.function.__name__
+    if name.startswith("test_gemm_"):
         if "gemm_path" not in metafunc.fixturenames:
             metafunc.fixturenames.append("gemm_path")
         metafunc.parametrize("gemm_path", ["small_kernel_on", "tiled_only"], indirect=True)
+    if name.startswith("test_sdpa_") and "row" not in name:
+        if "sdpa_path" not in metafunc.fixturenames:
+            metafunc.fixturenames.append("sdpa_path")
+        metafunc.parametrize("sdpa_path", ["tile16_on", "tile32_only"], indirect=True)
 
 
 def dev(a):

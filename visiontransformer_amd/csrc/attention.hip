@@ -748,6 +748,8 @@ int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   hipStream_t st = vitk::as_stream(stream);
   // 16-byte accesses where every pointer, pitch and dh allow them (all ViT configurations); the
   // scalar variant exists once, at the full 64-wide head tile
+  if (vitk::sdpa_fwd16_applies(N, dh, p.vec != 0, scale, ld_qkv))  // head dimensions 33..64: 16-row tiles, four heads per workgroup
+    return vitk::sdpa_fwd16_launch(q, k, v, ld_qkv, B, H, N, dh, scale, out, ld_out, stats, st);
   if (!p.vec) return launch_fwd<64, false>(p, (int)blocks, st);
   if (dh <= 16) return launch_fwd<16, true>(p, (int)blocks, st);
   if (dh <= 32) return launch_fwd<32, true>(p, (int)blocks, st);

@@ -25,6 +25,11 @@ int norm_static_setup();
 bool gemm_small_applies(const vitk_gemm_args *a);
 int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st);
 
+// Forward attention on 16-row tiles (attention16.hip): whether vitk_sdpa_fwd routes a call to it, and the launch.
+bool sdpa_fwd16_applies(int N, int dh, bool vec, float scale, long long ld);
+int sdpa_fwd16_launch(const float *q, const float *k, const float *v, long long ld, int B, int H, int N, int dh,
+                      float scale, float *out, long long ldo, float *stats, hipStream_t st);
+
 // Compute units of the current device (hipDeviceProp_t::multiProcessorCount), cached per device;
 // 256 if the query fails.
 int cu_count();

@@ -48,6 +48,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_int64), C.c_int]),
     "vitk_gemm_variant_name": (C.c_char_p, [C.c_int]),
     "vitk_gemm_small_enable": (C.c_int, [C.c_int]),
+    "vitk_sdpa_tile16_enable": (C.c_int, [C.c_int]),
     "vitk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "vitk_colsum_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "vitk_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
@@ -177,6 +178,11 @@ def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=Non
 def gemm_small(enable):
     """Route small problems to the one-wave-per-tile kernel (the default) or keep them on the tiled one."""
     check(dll().vitk_gemm_small_enable(int(enable)))
+
+
+def sdpa_tile16(enable):
+    """Forward attention of head dimensions 33..64 on 16-row tiles (the default) or on the 32-row kernel."""
+    check(dll().vitk_sdpa_tile16_enable(int(enable)))
 
 
 def gemm_profile(enable):
