@@ -229,6 +229,10 @@ int vitk_sdpa_supported(int32_t N, int32_t dh);
  * every round).  on = 0 keeps them on the 32-row kernel that serves the other head sizes (tests,
  * measurements); the default is on.  Same results to rounding.  Process-wide. */
 int vitk_sdpa_tile16_enable(int on);
+/* The same switch for the backward (one launch per call in both forms; the 16-row form deals the
+ * key blocks of several heads to the waves of a workgroup: as many heads as it takes for every
+ * workgroup to be resident at once, or exactly `on` heads when on >= 2 -- for tests). */
+int vitk_sdpa_bwd_tile16_enable(int on);
 int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv, int32_t B, int32_t H, int32_t N,
                   int32_t dh, float scale, float *out, int64_t ld_out, float *stats, vitk_stream_t stream);
 size_t vitk_sdpa_bwd_workspace_bytes(int32_t B, int32_t H, int32_t N);

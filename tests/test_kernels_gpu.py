@@ -36,9 +36,12 @@ def gemm_path(request, K):
 
 @pytest.fixture
 def sdpa_path(request, K):
-    """Every test_sdpa_* runs twice: head dimensions 33..64 on the 16-row-tile forward (the default)
-    and on the 32-row-tile forward that serves the other head sizes."""
-    K.sdpa_tile16(request.param == "tile16_on")
+    """Every test_sdpa_* runs three times: head dimensions 33..64 on the 16-row-tile kernels (the
+    default; the backward then gives every workgroup one head at these sizes), on the 32-row-tile
+    kernels that serve the other head sizes, and with the 16-row backward dealing the key blocks
+    of three heads to a workgroup (the large-batch configuration: rounds that span two heads, dQ
+    accumulated across rounds)."""
+    K.sdpa_tile16({"tile16_on": 1, "tile32_only": 0, "tile16_bwd_3_heads_per_workgroup": 3}[request.param])
     yield request.param
     K.sdpa_tile16(True)
 
@@ -52,7 +55,7 @@ def pytest_generate_tests(metafunc):
     if name.startswith("test_sdpa_") and "row" not in name:
         if "sdpa_path" not in metafunc.fixturenames:
             metafunc.fixturenames.append("sdpa_path")
-        metafunc.parametrize("sdpa_path", ["tile16_on", "tile32_only"], indirect=True)
+        metafunc.parametrize("sdpa_path", ["tile16_on", "tile32_only", "tile16_bwd_3_heads_per_workgroup"], indirect=True)
 
 
 def dev(a):
@@ -672,7 +675,7 @@ def heads_of(x, B, N, H, dh, col0):
 @pytest.mark.parametrize("B,H,N,dh,pad", [(2, 3, 197, 64, 0), (3, 8, 5, 12, 0), (2, 6, 17, 32, 0), (1, 2, 256, 64, 0),
                                           (2, 2, 33, 20, 1), (1, 1, 1, 4, 0), (2, 4, 50, 16, 0), (1, 3, 129, 48, 3),
                                           (2, 2, 64, 7, 0), (2, 2, 100, 48, 0), (1, 4, 33, 64, 0), (1, 1, 1, 64, 0),
-                                          (3, 2, 224, 40, 0)])
+                                          (3, 2, 224, 40, 0), (2, 7, 197, 64, 0), (5, 1, 49, 36, 0)])
 @pytest.mark.parametrize("dk_mode", ["reference", "exact"])
 def test_sdpa_fused_matches_float64(K, B, H, N, dh, pad, dk_mode):
     D, M = H * dh, B * N

@@ -1,0 +1,410 @@
+// Fused scaled-dot-product attention backward for head dimensions 33..64 on
+// v_mfma_f32_16x16x4_f32 with 16-row granularity (reference: src/layers/MultiHeadAttention.cpp:
+// 160-308): dQ, dK, dV from Q, K, V, O, dO and the row statistics of the forward, one launch,
+// 10 N^2 dh FLOP per head, nothing of size N^2 in memory.
+//
+// Work split.  The unit of work is one block of 16 keys of one head: a wave keeps that block's K
+// and V fragments and its dK^T / dV^T accumulators in registers and sweeps over the head's query
+// tiles (16 queries each), which stream through a two-stage LDS ring.  197 tokens are 13 blocks;
+// a workgroup of 4 waves owns several heads and deals their blocks to its waves round by round
+// (4 consecutive blocks per round, which touch at most two heads), so every wave has work in
+// every round but the last.  Per (query tile, key block) a wave forms S and dP ONCE, in the plain
+// orientation [query][key], and uses them three ways:
+//   dV^T[d][key] += dO^T P      and     dK^T[d][key] += Q^T dS      straight from the accumulator
+//   registers (register r of lane (c, g) is row 4g + r = the contraction index the next product
+//   wants from lane group g), and, after a 1 KB transpose of dS through a wave-private LDS
+//   buffer, its share of dQ^T[d][query] = K^T dS^T.
+// The (at most four) partial dQ tiles of a step are summed in wave order through LDS by all 256
+// threads and written to dQ; a head's blocks are spread over several rounds, so from the head's
+// second round on the sum is added to what the same thread stored before (plain load + store by
+// one thread: fixed order, no atomics, bitwise reproducible).
+//
+// The matrix cores and the vector ALU of a SIMD do not overlap on fp32 work, so the loop carries
+// no per-lane address arithmetic: global reads go through buffer descriptors (scalar base per
+// head, constant per-lane offset, scalar tile offset; rows past the sequence read as zeros), the
+// position in the list of blocks lives in scalar registers, and the row statistics {max * log2 e,
+// 1 / sum, sum_d dO * O} of the (at most two) live heads are prepared once per head in LDS.
+//
+// LDS tile layout: [16 rows][69 floats].  Operand reads by row (A[i = c][k]: row c, column
+// 16g + step) are conflict-free for any odd pitch; reads by column (A[i = c][k]: row 4g + r,
+// column 16 dt + c) want the two lane groups of a half-wave 16 banks apart, which 69 misses for 4
+// lanes of 32 (2-way) -- cheaper than keeping two copies of every tile.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TP = 69;                    // tile row pitch
+constexpr int TILE = 16 * TP;             // one 16 x 64 tile
+constexpr int SLOT = 2 * TILE;            // Q tile + dO tile of one head
+constexpr int STAGE = 2 * SLOT;           // two heads may be live in one round
+constexpr int PBP = 68, PB = 16 * PBP;    // one wave's partial dQ tile [query][d]
+constexpr int TBP = 20, TB = 16 * TBP;    // one wave's dS transpose buffer [query][key]
+constexpr int MAXN = 256;
+constexpr int F_RING = 0, F_PB = F_RING + 2 * STAGE, F_TB = F_PB + 4 * PB, F_ST = F_TB + 4 * TB;
+constexpr int F_TOTAL = F_ST + 2 * 3 * MAXN;  // statistics: [head parity][max2 | 1/sum | dsum][query]
+
+struct Bwd16Params {
+  const float *q, *k, *v;   // element (b, n, h, d) at ptr[(b*N + n)*ld + h*dh + d]
+  long long ld;
+  const float *o, *dout;    // forward output and its gradient (ldo)
+  long long ldo;
+  const float *stats;       // [B*H][N][2]: row max of the scaled scores, row sum of exp
+  float *dq, *dk, *dv;      // gradients (ldg)
+  long long ldg;
+  int B, H, N, dh;
+  float scale;
+  int dk_mode;
+  int hpw;                  // heads per workgroup
+};
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ f32x4 buf_quad(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0));
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, soff, 0));
+}
+
+__global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int BH = p.B * p.H;
+  const int head0 = blockIdx.x * p.hpw, nh = min(p.hpw, BH - head0);
+  const int nblk = (p.N + 15) / 16, items = nh * nblk, rounds = (items + 3) / 4;
+  const int nqt = nblk;  // query tiles of 16
+  constexpr unsigned kOutside = 0x7fffff00u;  // beyond any descriptor: reads as zero
+  const float sl2 = p.scale * 1.44269504088896340736f;
+
+  // one descriptor per (tensor, head): it ends with the head's last row, so rows >= N read as zeros
+  const int bytes_qkv = (int)(((long long)(p.N - 1) * p.ld + p.dh) * 4);
+  const int bytes_o = (int)(((long long)(p.N - 1) * p.ldo + p.dh) * 4);
+  const int bytes_g = (int)(((long long)(p.N - 1) * p.ldg + p.dh) * 4);
+  auto rsrc = [&](const float *ptr, long long off, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ptr + off), 0, bytes, 0x00020000);
+  };
+  // head index inside the workgroup -> element offsets of the head in the three pitch families
+  auto offs = [&](int h, long long *o_qkv, long long *o_o, long long *o_g) {
+    const int hd = head0 + h, b = hd / p.H, hm = hd % p.H;
+    *o_qkv = (long long)b * p.N * p.ld + (long long)hm * p.dh;
+    *o_o = (long long)b * p.N * p.ldo + (long long)hm * p.dh;
+    *o_g = (long long)b * p.N * p.ldg + (long long)hm * p.dh;
+  };
+
+  // ---- per-thread constants ----
+  // staging / reduction role: thread t <-> row t/16, columns 4*(t%16) .. +3 of a 16 x 64 tile
+  const int sr = threadIdx.x >> 4, sc = (threadIdx.x & 15) * 4;
+  const bool sc_ok = sc < p.dh;
+  const unsigned sv_q = sc_ok ? (unsigned)((sr * p.ld + sc) * 4) : kOutside;
+  const unsigned sv_o = sc_ok ? (unsigned)((sr * p.ldo + sc) * 4) : kOutside;
+  const unsigned sv_g = sc_ok ? (unsigned)((sr * p.ldg + sc) * 4) : kOutside;
+  const int tile_q = (int)(16 * p.ld * 4), tile_o = (int)(16 * p.ldo * 4), tile_g = (int)(16 * p.ldg * 4);
+  float *const st_dst = lds + F_RING + sr * TP + sc;
+  // compute role: operand reads by row (a1) and by column (a2), see the layout note above
+  const int a1 = c * TP + 16 * g, a2 = (4 * g) * TP + c;
+  float *const tb = lds + F_TB + wave * TB;
+  float *const pb = lds + F_PB + wave * PB;
+  float *const stat = lds + F_ST;
+  // fragments of a key block: (row c, columns 16g + i) and (rows 4g + r, columns 16 dt + c)
+  unsigned fv_row[4], fv_col[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    fv_row[i] = 16 * g + 4 * i < p.dh ? (unsigned)((c * p.ld + 16 * g + 4 * i) * 4) : kOutside;
+    fv_col[i] = 16 * i + c < p.dh ? (unsigned)(((4 * g) * p.ld + 16 * i + c) * 4) : kOutside;  // (i = dt)
+  }
+  const int row_bytes = (int)(p.ld * 4);
+
+  // ---- position bookkeeping (scalar): item = (head h, key block q), 4 items per round ----
+  struct Pos {
+    int h, q;
+  };
+  auto advance = [&](Pos &x, int by) {
+    x.q += by;
+    while (x.q >= nblk) x.q -= nblk, ++x.h;
+  };
+  Pos lo{0, 0}, my{0, 0};
+  advance(my, wave);
+
+  f32x4 kf[4], vf[4], kt[4];  // this round's key block; kt[r][dt] = K[16 q + 4g + r][16 dt + c]
+  auto load_block = [&](const Pos &x, f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&t)[4]) {
+    long long oq, oo, og;
+    offs(x.h, &oq, &oo, &og);
+    const __amdgpu_buffer_rsrc_t rk = rsrc(p.k, oq, bytes_qkv), rv = rsrc(p.v, oq, bytes_qkv);
+    const int so = x.q * tile_q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = buf_quad(rk, fv_row[i], so);
+      b[i] = buf_quad(rv, fv_row[i], so);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) t[r][dt] = buf_f32(rk, fv_col[dt], so + r * row_bytes);
+  };
+
+  // Q and dO tiles of query tile qt of the round's head(s) -> registers -> ring stage
+  f32x4 lq[2], lg[2];
+  auto load_tiles = [&](long long oq0, long long oo0, long long oq1, long long oo1, bool two_, int qt) {
+    lq[0] = buf_quad(rsrc(p.q, oq0, bytes_qkv), sv_q, qt * tile_q);
+    lg[0] = buf_quad(rsrc(p.dout, oo0, bytes_o), sv_o, qt * tile_o);
+    if (two_) {  // workgroup-uniform
+      lq[1] = buf_quad(rsrc(p.q, oq1, bytes_qkv), sv_q, qt * tile_q);
+      lg[1] = buf_quad(rsrc(p.dout, oo1, bytes_o), sv_o, qt * tile_o);
+    }
+  };
+  auto store_tiles = [&](int stage, bool two) {
+    float *d = st_dst + stage * STAGE;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d[e] = lq[0][e];
+      d[TILE + e] = lg[0][e];
+    }
+    if (two) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d[SLOT + e] = lq[1][e];
+        d[SLOT + TILE + e] = lg[1][e];
+      }
+    }
+  };
+
+  // Row statistics of head h into its LDS slot (h & 1): max * log2(e), 1 / sum, sum_d dO * O.
+  // All 256 threads; 7 query tiles of loads in flight at a time.
+  auto fill_stats = [&](int h) {
+    long long oq, oo, og;
+    offs(h, &oq, &oo, &og);
+    const __amdgpu_buffer_rsrc_t rg_ = rsrc(p.dout, oo, bytes_o), ro_ = rsrc(p.o, oo, bytes_o);
+    float *dst = stat + (h & 1) * 3 * MAXN;
+    const float *sp = p.stats + (long long)(head0 + h) * p.N * 2;
+    constexpr int G = 7;
+    for (int t0 = 0; t0 < nqt; t0 += G) {
+      f32x4 a[G], b[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        a[i] = buf_quad(rg_, sv_o, (t0 + i) * tile_o);  // (tiles past the sequence read as zeros)
+        b[i] = buf_quad(ro_, sv_o, (t0 + i) * tile_o);
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        float part = (a[i][0] * b[i][0] + a[i][1] * b[i][1]) + (a[i][2] * b[i][2] + a[i][3] * b[i][3]);
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) part += __shfl_xor(part, m, 16);
+        const int row = 16 * (t0 + i) + sr;
+        if ((threadIdx.x & 15) == 0 && row < MAXN && t0 + i < nqt) {
+          const bool ok = row < p.N;
+          const float mx = ok ? sp[2 * row] : 0.f, sm = ok ? sp[2 * row + 1] : 1.f;
+          dst[row] = mx * 1.44269504088896340736f;
+          dst[MAXN + row] = ok ? 1.0f / sm : 0.f;
+          dst[2 * MAXN + row] = ok ? part : 0.f;
+        }
+      }
+    }
+  };
+
+  // ---- prologue: first key block, first query tile, statistics of the first head(s) ----
+  int ready = -1;  // highest head whose statistics are in LDS
+  bool two = lo.q + 3 >= nblk && lo.h + 1 < nh;
+  if (wave < items) load_block(my, kf, vf, kt);
+  long long oq_lo, oo_lo, og_lo, oq_hi, oo_hi, og_hi;  // element offsets of the round's head(s)
+  offs(lo.h, &oq_lo, &oo_lo, &og_lo);
+  offs(lo.h + 1, &oq_hi, &oo_hi, &og_hi);
+  load_tiles(oq_lo, oo_lo, oq_hi, oo_hi, two, 0);
+  store_tiles(0, two);
+  int stage = 0;
+
+  for (int round = 0; round < rounds; ++round) {
+    const int na = min(4, items - 4 * round);        // waves with a block in this round
+    const bool active = wave < na;                   // wave-uniform
+    const int k0 = min(na, nblk - lo.q);             // waves [0, k0) work on head lo.h, [k0, na) on the next
+    const int slot = (active && my.h != lo.h) ? 1 : 0;
+    const bool accumulate = lo.q != 0;               // head lo.h has stored dQ in an earlier round
+    // statistics of heads entering this round (a head's slot is free: the head two before it is done)
+    {
+      const int need = two ? lo.h + 1 : lo.h;
+      while (ready < need) fill_stats(++ready);
+      __syncthreads();  // statistics and the staged tile are visible
+    }
+    Pos nlo = lo, nmy = my;
+    advance(nlo, 4);
+    advance(nmy, 4);
+    const bool ntwo = nlo.q + 3 >= nblk && nlo.h + 1 < nh;
+    const bool more_rounds = round + 1 < rounds;
+    // the next round's key block travels during this one
+    f32x4 nkf[4], nvf[4], nkt[4];
+    if (more_rounds && wave + 4 * (round + 1) < items) load_block(nmy, nkf, nvf, nkt);
+
+    long long noq_lo, noo_lo, nog_lo, noq_hi, noo_hi, nog_hi;  // the next round's
+    offs(nlo.h, &noq_lo, &noo_lo, &nog_lo);
+    offs(nlo.h + 1, &noq_hi, &noo_hi, &nog_hi);
+    const __amdgpu_buffer_rsrc_t rdq_lo = rsrc(p.dq, og_lo, bytes_g);
+    const bool key_ok = 16 * my.q + c < p.N;
+    const float *mystat = stat + (my.h & 1) * 3 * MAXN + 4 * g;
+
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = zero4(), dv[dt] = zero4();
+
+    for (int qt = 0; qt < nqt; ++qt) {
+      const bool last = qt + 1 == nqt;
+      // next in the stream: this round's next query tile, or the next round's first
+      if (!last) load_tiles(oq_lo, oo_lo, oq_hi, oo_hi, two, qt + 1);
+      else if (more_rounds) load_tiles(noq_lo, noo_lo, noq_hi, noo_hi, ntwo, 0);
+      f32x4 old = zero4();
+      if (accumulate) old = buf_quad(rdq_lo, sv_g, qt * tile_g);
+
+      if (active) {
+        const float *qs = lds + F_RING + stage * STAGE + slot * SLOT, *gs = qs + TILE;
+        // S = Q K^T and dP = dO V^T, both [query][key]
+        f32x4 s = zero4(), dp = zero4();
+        {
+          float qa[16], ga[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) qa[i] = qs[a1 + i], ga[i] = gs[a1 + i];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i], kf[i / 4][i % 4], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i], vf[i / 4][i % 4], dp, 0, 0, 0);
+          }
+        }
+        // P from the saved statistics; dS = P (dP - dsum) scale
+        const f32x4 m2 = *reinterpret_cast<const f32x4 *>(mystat + 16 * qt);
+        const f32x4 li = *reinterpret_cast<const f32x4 *>(mystat + MAXN + 16 * qt);
+        const f32x4 ds_ = *reinterpret_cast<const f32x4 *>(mystat + 2 * MAXN + 16 * qt);
+        f32x4 pr, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -m2[r])) * li[r];
+          pr[r] = key_ok ? e : 0.f;
+          ds[r] = (pr[r] * (dp[r] - ds_[r])) * p.scale;
+          tb[(4 * g + r) * TBP + c] = ds[r];  // dS[query][key], read back transposed below
+        }
+        // dV^T += dO^T P and dK^T += Q^T dS (contraction over the 16 queries)
+        {
+          float qa[16], ga[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) qa[i] = qs[a2 + (i / 4) * TP + 16 * (i % 4)], ga[i] = gs[a2 + (i / 4) * TP + 16 * (i % 4)];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            dv[i % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i], pr[i / 4], dv[i % 4], 0, 0, 0);
+            dk[i % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i], ds[i / 4], dk[i % 4], 0, 0, 0);
+          }
+        }
+        // this block's share of dQ^T[d][query] = K^T dS^T (contraction over the 16 keys)
+        const f32x4 dst = *reinterpret_cast<const f32x4 *>(tb + c * TBP + 4 * g);  // dS[query c][keys 4g ..]
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = zero4();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          dq[i % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[i / 4][i % 4], dst[i / 4], dq[i % 4], 0, 0, 0);
+        // register r of dq[dt] is dQ[query c][16 dt + 4g + r]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4 *>(pb + c * PBP + 16 * dt + 4 * g) = dq[dt];
+      }
+      __syncthreads();  // every wave is done with this query tile; the partial dQ tiles are in LDS
+
+      // sum the partial tiles in wave order; thread t owns query row t/16, columns 4*(t%16) ..
+      {
+        const float *src = lds + F_PB + sr * PBP + sc;
+        const int row = 16 * qt + sr;
+        f32x4 sum = old;
+        for (int w = 0; w < k0; ++w) sum += *reinterpret_cast<const f32x4 *>(src + w * PB);
+        if (row < p.N && sc_ok) *reinterpret_cast<f32x4 *>(p.dq + og_lo + (long long)row * p.ldg + sc) = sum;
+        if (k0 < na) {  // the round's second head: always its first round
+          f32x4 sum2 = zero4();
+          for (int w = k0; w < na; ++w) sum2 += *reinterpret_cast<const f32x4 *>(src + w * PB);
+          if (row < p.N && sc_ok) *reinterpret_cast<f32x4 *>(p.dq + og_hi + (long long)row * p.ldg + sc) = sum2;
+        }
+      }
+      stage ^= 1;
+      if (!last) store_tiles(stage, two);
+      else if (more_rounds) store_tiles(stage, ntwo);
+      __syncthreads();  // next tile staged; partial buffers free again
+    }
+
+    // ---- this block's dK and dV: register r of d*[dt] is row (key) c, column 16 dt + 4g + r ----
+    if (active && key_ok) {
+      long long oq, oo, og;
+      offs(my.h, &oq, &oo, &og);
+      const int key = 16 * my.q + c;
+      float *dvrow = p.dv + og + (long long)key * p.ldg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        if (16 * dt + 4 * g < p.dh) *reinterpret_cast<f32x4 *>(dvrow + 16 * dt + 4 * g) = dv[dt];
+      if (p.dk_mode == VITK_DK_EXACT) {
+        float *dkrow = p.dk + og + (long long)key * p.ldg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          if (16 * dt + 4 * g < p.dh) *reinterpret_cast<f32x4 *>(dkrow + 16 * dt + 4 * g) = dk[dt];
+      } else {
+        // The reference forms Q^T dS as [dh][N] per head and re-reads that buffer as [N][dh]
+        // (src/layers/MultiHeadAttention.cpp:207-222): element (d, key) lands at flat index d*N + key.
+        float *base = p.dk + og;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 16 * dt + 4 * g + r;
+            if (d < p.dh) {
+              const int f = d * p.N + key;
+              const int fr = p.dh == 64 ? f >> 6 : f / p.dh, fc = p.dh == 64 ? f & 63 : f % p.dh;
+              base[(long long)fr * p.ldg + fc] = dk[dt][r];
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kf[i] = nkf[i], vf[i] = nvf[i], kt[i] = nkt[i];
+    lo = nlo, my = nmy, two = ntwo;
+    oq_lo = noq_lo, oo_lo = noo_lo, og_lo = nog_lo, oq_hi = noq_hi, oo_hi = noo_hi, og_hi = nog_hi;
+  }
+}
+
+int g_bwd16_mode = 1;  // 0 = off, 1 = on (heads per workgroup from the device size), n >= 2 = on with n heads per workgroup
+
+}  // namespace
+
+namespace vitk {
+
+// (four consecutive blocks must span at most two heads: at least 4 blocks of 16 per head; the
+// per-lane offsets into a head are 32-bit)
+bool sdpa_bwd16_applies(int N, int dh, bool vec, long long ld, long long ldo, long long ldg) {
+  const long long m = ld > ldo ? (ld > ldg ? ld : ldg) : (ldo > ldg ? ldo : ldg);
+  return g_bwd16_mode != 0 && vec && dh > 32 && dh <= 64 && N >= 49 && N <= MAXN && (long long)N * m * 4 < (1ll << 30);
+}
+
+int sdpa_bwd16_launch(const float *q, const float *k, const float *v, long long ld, const float *o, const float *dout,
+                      long long ldo, const float *stats, int B, int H, int N, int dh, float scale, int dk_mode,
+                      float *dq, float *dk, float *dv, long long ldg, hipStream_t st) {
+  const size_t lds = F_TOTAL * sizeof(float);
+  static bool configured = false;  // raise the dynamic LDS limit once (idempotent; set per process)
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd16_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    VITK_REQUIRE(e == hipSuccess, "vitk_sdpa_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  Bwd16Params p;
+  p.q = q; p.k = k; p.v = v; p.ld = ld; p.o = o; p.dout = dout; p.ldo = ldo; p.stats = stats;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.ldg = ldg;
+  p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale; p.dk_mode = dk_mode;
+  // two workgroups fit a CU: give each enough heads that all of them are resident at once
+  const int bh = B * H, slots = 2 * cu_count();
+  int hpw = (bh + slots - 1) / slots;
+  if (hpw < 1) hpw = 1;
+  if (hpw > 8) hpw = 8;
+  if (g_bwd16_mode >= 2) hpw = g_bwd16_mode;
+  p.hpw = hpw;
+  hipLaunchKernelGGL(sdpa_bwd16_kernel, dim3((unsigned)((bh + hpw - 1) / hpw)), dim3(256), lds, st, p);
+  return check_launch("vitk_sdpa_bwd");
+}
+
+}  // namespace vitk
+
+extern "C" int vitk_sdpa_bwd_tile16_enable(int on) {
+  g_bwd16_mode = on < 0 ? 0 : on;
+  return 0;
+}

@@ -49,6 +49,7 @@ SIGNATURES = {
     "vitk_gemm_variant_name": (C.c_char_p, [C.c_int]),
     "vitk_gemm_small_enable": (C.c_int, [C.c_int]),
     "vitk_sdpa_tile16_enable": (C.c_int, [C.c_int]),
+    "vitk_sdpa_bwd_tile16_enable": (C.c_int, [C.c_int]),
     "vitk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "vitk_colsum_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "vitk_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
@@ -181,8 +182,9 @@ def gemm_small(enable):
 
 
 def sdpa_tile16(enable):
-    """Forward attention of head dimensions 33..64 on 16-row tiles (the default) or on the 32-row kernel."""
-    check(dll().vitk_sdpa_tile16_enable(int(enable)))
+    """Attention (forward and backward) of head dimensions 33..64 on 16-row tiles (the default) or on the 32-row kernels."""
+    check(dll().vitk_sdpa_tile16_enable(int(bool(enable))))
+    check(dll().vitk_sdpa_bwd_tile16_enable(int(enable)))  # (n >= 2: n heads per workgroup, for tests)
 
 
 def gemm_profile(enable):
