@@ -787,7 +787,7 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   p.vec = all_vec({q, k, v, out, dout, dq, dk, dv}, {ld_qkv, ld_out, ld_dqkv, dh});
   hipStream_t st = vitk::as_stream(stream);
   const dim3 grid((unsigned)blocks);
-  if (vitk::sdpa_bwd16_applies(N, dh, p.vec != 0, ld_qkv, ld_out, ld_dqkv))  // 16-row tiles, several heads per workgroup
+  if (vitk::sdpa_bwd16_applies(B, N, dh, p.vec != 0, ld_qkv, ld_out, ld_dqkv))  // 16-row tiles, several heads per workgroup
     return vitk::sdpa_bwd16_launch(q, k, v, ld_qkv, out, dout, ld_out, stats, B, H, N, dh, scale, dk_mode, dq, dk, dv,
                                    ld_dqkv, st);
   if (!p.vec) return launch_bwd<64, false>(p, grid, st);

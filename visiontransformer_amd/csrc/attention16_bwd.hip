@@ -42,17 +42,17 @@ constexpr int STAGE = 2 * SLOT;           // two heads may be live in one round
 constexpr int PBP = 68, PB = 16 * PBP;    // one wave's partial dQ tile [query][d]
 constexpr int TBP = 20, TB = 16 * TBP;    // one wave's dS transpose buffer [query][key]
 constexpr int MAXN = 256;
-constexpr int F_RING = 0, F_PB = F_RING + 2 * STAGE, F_TB = F_PB + 4 * PB, F_ST = F_TB + 4 * TB;
+constexpr int F_RING = 0, F_PB = F_RING + 2 * STAGE, F_TB = F_PB + 2 * 4 * PB, F_ST = F_TB + 4 * TB;  // (partial tiles: two sets)
 constexpr int F_TOTAL = F_ST + 2 * 3 * MAXN;  // statistics: [head parity][max2 | 1/sum | dsum][query]
 
 struct Bwd16Params {
   const float *q, *k, *v;   // element (b, n, h, d) at ptr[(b*N + n)*ld + h*dh + d]
-  long long ld;
+  int ld;                   // (pitches and whole-tensor element counts fit 31 bits: checked by the launcher)
   const float *o, *dout;    // forward output and its gradient (ldo)
-  long long ldo;
+  int ldo;
   const float *stats;       // [B*H][N][2]: row max of the scaled scores, row sum of exp
   float *dq, *dk, *dv;      // gradients (ldg)
-  long long ldg;
+  int ldg;
   int B, H, N, dh;
   float scale;
   int dk_mode;
@@ -63,6 +63,10 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 __device__ __forceinline__ f32x4 buf_quad(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0));
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store_quad(f32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, soff, 0);
 }
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, soff, 0));
@@ -83,15 +87,15 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
   const int bytes_qkv = (int)(((long long)(p.N - 1) * p.ld + p.dh) * 4);
   const int bytes_o = (int)(((long long)(p.N - 1) * p.ldo + p.dh) * 4);
   const int bytes_g = (int)(((long long)(p.N - 1) * p.ldg + p.dh) * 4);
-  auto rsrc = [&](const float *ptr, long long off, int bytes) {
+  auto rsrc = [&](const float *ptr, int off, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ptr + off), 0, bytes, 0x00020000);
   };
   // head index inside the workgroup -> element offsets of the head in the three pitch families
-  auto offs = [&](int h, long long *o_qkv, long long *o_o, long long *o_g) {
+  auto offs = [&](int h, int *o_qkv, int *o_o, int *o_g) {
     const int hd = head0 + h, b = hd / p.H, hm = hd % p.H;
-    *o_qkv = (long long)b * p.N * p.ld + (long long)hm * p.dh;
-    *o_o = (long long)b * p.N * p.ldo + (long long)hm * p.dh;
-    *o_g = (long long)b * p.N * p.ldg + (long long)hm * p.dh;
+    *o_qkv = b * p.N * p.ld + hm * p.dh;
+    *o_o = b * p.N * p.ldo + hm * p.dh;
+    *o_g = b * p.N * p.ldg + hm * p.dh;
   };
 
   // ---- per-thread constants ----
@@ -106,7 +110,6 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
   // compute role: operand reads by row (a1) and by column (a2), see the layout note above
   const int a1 = c * TP + 16 * g, a2 = (4 * g) * TP + c;
   float *const tb = lds + F_TB + wave * TB;
-  float *const pb = lds + F_PB + wave * PB;
   float *const stat = lds + F_ST;
   // fragments of a key block: (row c, columns 16g + i) and (rows 4g + r, columns 16 dt + c)
   unsigned fv_row[4], fv_col[4];
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
 
   f32x4 kf[4], vf[4], kt[4];  // this round's key block; kt[r][dt] = K[16 q + 4g + r][16 dt + c]
   auto load_block = [&](const Pos &x, f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&t)[4]) {
-    long long oq, oo, og;
+    int oq, oo, og;
     offs(x.h, &oq, &oo, &og);
     const __amdgpu_buffer_rsrc_t rk = rsrc(p.k, oq, bytes_qkv), rv = rsrc(p.v, oq, bytes_qkv);
     const int so = x.q * tile_q;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
 
   // Q and dO tiles of query tile qt of the round's head(s) -> registers -> ring stage
   f32x4 lq[2], lg[2];
-  auto load_tiles = [&](long long oq0, long long oo0, long long oq1, long long oo1, bool two_, int qt) {
+  auto load_tiles = [&](int oq0, int oo0, int oq1, int oo1, bool two_, int qt) {
     lq[0] = buf_quad(rsrc(p.q, oq0, bytes_qkv), sv_q, qt * tile_q);
     lg[0] = buf_quad(rsrc(p.dout, oo0, bytes_o), sv_o, qt * tile_o);
     if (two_) {  // workgroup-uniform
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
   // Row statistics of head h into its LDS slot (h & 1): max * log2(e), 1 / sum, sum_d dO * O.
   // All 256 threads; 7 query tiles of loads in flight at a time.
   auto fill_stats = [&](int h) {
-    long long oq, oo, og;
+    int oq, oo, og;
     offs(h, &oq, &oo, &og);
     const __amdgpu_buffer_rsrc_t rg_ = rsrc(p.dout, oo, bytes_o), ro_ = rsrc(p.o, oo, bytes_o);
     float *dst = stat + (h & 1) * 3 * MAXN;
@@ -208,12 +211,41 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
   int ready = -1;  // highest head whose statistics are in LDS
   bool two = lo.q + 3 >= nblk && lo.h + 1 < nh;
   if (wave < items) load_block(my, kf, vf, kt);
-  long long oq_lo, oo_lo, og_lo, oq_hi, oo_hi, og_hi;  // element offsets of the round's head(s)
-  offs(lo.h, &oq_lo, &oo_lo, &og_lo);
-  offs(lo.h + 1, &oq_hi, &oo_hi, &og_hi);
-  load_tiles(oq_lo, oo_lo, oq_hi, oo_hi, two, 0);
-  store_tiles(0, two);
-  int stage = 0;
+  {
+    int oq0, oo0, og0, oq1, oo1, og1;
+    offs(0, &oq0, &oo0, &og0);
+    offs(1, &oq1, &oo1, &og1);
+    load_tiles(oq0, oo0, oq1, oo1, two, 0);
+    store_tiles(0, two);
+  }
+  int stage = 0;  // ring stage of the tile about to be used = set of partial tiles about to be written
+
+  // The partial dQ tiles of a step are summed at the start of the NEXT step (one barrier per step:
+  // the sets alternate), possibly the first step of the next round: what that needs is kept here.
+  bool pend = false;
+  int pend_k0 = 0, pend_na = 0, pend_row0 = 0;
+  int pend_lo = 0, pend_hi = 0;
+  f32x4 pend_old = zero4();
+  auto reduce_pending = [&](int set) {
+    // sum in wave order; thread t owns query row t/16, columns 4*(t%16) .. (rows past the sequence
+    // and columns past the head fall outside the descriptor: the store is dropped)
+    const float *src = lds + F_PB + set * 4 * PB + sr * PBP + sc;
+    const int so = pend_row0 * (tile_g / 16);
+    if (pend_k0 == 4) {  // the usual round: four blocks of one head
+      const f32x4 p0 = *reinterpret_cast<const f32x4 *>(src), p1 = *reinterpret_cast<const f32x4 *>(src + PB);
+      const f32x4 p2 = *reinterpret_cast<const f32x4 *>(src + 2 * PB), p3 = *reinterpret_cast<const f32x4 *>(src + 3 * PB);
+      buf_store_quad((((pend_old + p0) + p1) + p2) + p3, rsrc(p.dq, pend_lo, bytes_g), sv_g, so);
+      return;
+    }
+    f32x4 sum = pend_old;
+    for (int w = 0; w < pend_k0; ++w) sum += *reinterpret_cast<const f32x4 *>(src + w * PB);
+    buf_store_quad(sum, rsrc(p.dq, pend_lo, bytes_g), sv_g, so);
+    if (pend_k0 < pend_na) {  // the round's second head: always its first round
+      f32x4 sum2 = zero4();
+      for (int w = pend_k0; w < pend_na; ++w) sum2 += *reinterpret_cast<const f32x4 *>(src + w * PB);
+      buf_store_quad(sum2, rsrc(p.dq, pend_hi, bytes_g), sv_g, so);
+    }
+  };
 
   for (int round = 0; round < rounds; ++round) {
     const int na = min(4, items - 4 * round);        // waves with a block in this round
@@ -224,8 +256,9 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
     // statistics of heads entering this round (a head's slot is free: the head two before it is done)
     {
       const int need = two ? lo.h + 1 : lo.h;
+      const bool fill = ready < need;
       while (ready < need) fill_stats(++ready);
-      __syncthreads();  // statistics and the staged tile are visible
+      if (fill || round == 0) __syncthreads();  // statistics (and the first staged tile) are visible
     }
     Pos nlo = lo, nmy = my;
     advance(nlo, 4);
@@ -236,9 +269,9 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
     f32x4 nkf[4], nvf[4], nkt[4];
     if (more_rounds && wave + 4 * (round + 1) < items) load_block(nmy, nkf, nvf, nkt);
 
-    long long noq_lo, noo_lo, nog_lo, noq_hi, noo_hi, nog_hi;  // the next round's
-    offs(nlo.h, &noq_lo, &noo_lo, &nog_lo);
-    offs(nlo.h + 1, &noq_hi, &noo_hi, &nog_hi);
+    int oq_lo, oo_lo, og_lo, oq_hi, oo_hi, og_hi;  // element offsets of the round's head(s)
+    offs(lo.h, &oq_lo, &oo_lo, &og_lo);
+    offs(lo.h + 1, &oq_hi, &oo_hi, &og_hi);
     const __amdgpu_buffer_rsrc_t rdq_lo = rsrc(p.dq, og_lo, bytes_g);
     const bool key_ok = 16 * my.q + c < p.N;
     const float *mystat = stat + (my.h & 1) * 3 * MAXN + 4 * g;
@@ -250,13 +283,22 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
     for (int qt = 0; qt < nqt; ++qt) {
       const bool last = qt + 1 == nqt;
       // next in the stream: this round's next query tile, or the next round's first
-      if (!last) load_tiles(oq_lo, oo_lo, oq_hi, oo_hi, two, qt + 1);
-      else if (more_rounds) load_tiles(noq_lo, noo_lo, noq_hi, noo_hi, ntwo, 0);
+      const bool stream_on = !last || more_rounds;
+      if (stream_on) {
+        int a0 = oq_lo, b0 = oo_lo, a1_ = oq_hi, b1 = oo_hi, unused;
+        if (last) {  // the tile that opens the next round
+          offs(nlo.h, &a0, &b0, &unused);
+          offs(nlo.h + 1, &a1_, &b1, &unused);
+        }
+        load_tiles(a0, b0, a1_, b1, last ? ntwo : two, last ? 0 : qt + 1);
+      }
       f32x4 old = zero4();
       if (accumulate) old = buf_quad(rdq_lo, sv_g, qt * tile_g);
+      if (pend) reduce_pending(stage ^ 1);
 
       if (active) {
         const float *qs = lds + F_RING + stage * STAGE + slot * SLOT, *gs = qs + TILE;
+        float *pb = lds + F_PB + (stage * 4 + wave) * PB;
         // S = Q K^T and dP = dO V^T, both [query][key]
         f32x4 s = zero4(), dp = zero4();
         {
@@ -304,30 +346,15 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4 *>(pb + c * PBP + 16 * dt + 4 * g) = dq[dt];
       }
-      __syncthreads();  // every wave is done with this query tile; the partial dQ tiles are in LDS
-
-      // sum the partial tiles in wave order; thread t owns query row t/16, columns 4*(t%16) ..
-      {
-        const float *src = lds + F_PB + sr * PBP + sc;
-        const int row = 16 * qt + sr;
-        f32x4 sum = old;
-        for (int w = 0; w < k0; ++w) sum += *reinterpret_cast<const f32x4 *>(src + w * PB);
-        if (row < p.N && sc_ok) *reinterpret_cast<f32x4 *>(p.dq + og_lo + (long long)row * p.ldg + sc) = sum;
-        if (k0 < na) {  // the round's second head: always its first round
-          f32x4 sum2 = zero4();
-          for (int w = k0; w < na; ++w) sum2 += *reinterpret_cast<const f32x4 *>(src + w * PB);
-          if (row < p.N && sc_ok) *reinterpret_cast<f32x4 *>(p.dq + og_hi + (long long)row * p.ldg + sc) = sum2;
-        }
-      }
+      if (stream_on) store_tiles(stage ^ 1, last ? ntwo : two);
+      pend = true, pend_k0 = k0, pend_na = na, pend_row0 = 16 * qt, pend_lo = og_lo, pend_hi = og_hi, pend_old = old;
       stage ^= 1;
-      if (!last) store_tiles(stage, two);
-      else if (more_rounds) store_tiles(stage, ntwo);
-      __syncthreads();  // next tile staged; partial buffers free again
+      __syncthreads();  // this step's partial tiles and the next step's query tile are in LDS
     }
 
     // ---- this block's dK and dV: register r of d*[dt] is row (key) c, column 16 dt + 4g + r ----
     if (active && key_ok) {
-      long long oq, oo, og;
+      int oq, oo, og;
       offs(my.h, &oq, &oo, &og);
       const int key = 16 * my.q + c;
       float *dvrow = p.dv + og + (long long)key * p.ldg;
@@ -359,8 +386,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) kf[i] = nkf[i], vf[i] = nvf[i], kt[i] = nkt[i];
     lo = nlo, my = nmy, two = ntwo;
-    oq_lo = noq_lo, oo_lo = noo_lo, og_lo = nog_lo, oq_hi = noq_hi, oo_hi = noo_hi, og_hi = nog_hi;
   }
+  if (pend) reduce_pending(stage ^ 1);
 }
 
 int g_bwd16_mode = 1;  // 0 = off, 1 = on (heads per workgroup from the device size), n >= 2 = on with n heads per workgroup
@@ -370,10 +397,11 @@ int g_bwd16_mode = 1;  // 0 = off, 1 = on (heads per workgroup from the device s
 namespace vitk {
 
 // (four consecutive blocks must span at most two heads: at least 4 blocks of 16 per head; the
-// per-lane offsets into a head are 32-bit)
-bool sdpa_bwd16_applies(int N, int dh, bool vec, long long ld, long long ldo, long long ldg) {
+// per-lane byte offsets into a head and the element offsets of the heads are 32-bit)
+bool sdpa_bwd16_applies(int B, int N, int dh, bool vec, long long ld, long long ldo, long long ldg) {
   const long long m = ld > ldo ? (ld > ldg ? ld : ldg) : (ldo > ldg ? ldo : ldg);
-  return g_bwd16_mode != 0 && vec && dh > 32 && dh <= 64 && N >= 49 && N <= MAXN && (long long)N * m * 4 < (1ll << 30);
+  return g_bwd16_mode != 0 && vec && dh > 32 && dh <= 64 && N >= 49 && N <= MAXN && (long long)N * m * 4 < (1ll << 30) &&
+         (long long)B * N * m < (1ll << 31);
 }
 
 int sdpa_bwd16_launch(const float *q, const float *k, const float *v, long long ld, const float *o, const float *dout,
@@ -388,8 +416,8 @@ int sdpa_bwd16_launch(const float *q, const float *k, const float *v, long long 
     configured = true;
   }
   Bwd16Params p;
-  p.q = q; p.k = k; p.v = v; p.ld = ld; p.o = o; p.dout = dout; p.ldo = ldo; p.stats = stats;
-  p.dq = dq; p.dk = dk; p.dv = dv; p.ldg = ldg;
+  p.q = q; p.k = k; p.v = v; p.ld = (int)ld; p.o = o; p.dout = dout; p.ldo = (int)ldo; p.stats = stats;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.ldg = (int)ldg;
   p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale; p.dk_mode = dk_mode;
   // two workgroups fit a CU: give each enough heads that all of them are resident at once
   const int bh = B * H, slots = 2 * cu_count();

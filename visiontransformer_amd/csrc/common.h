@@ -31,7 +31,7 @@ int sdpa_fwd16_launch(const float *q, const float *k, const float *v, long long 
                       float scale, float *out, long long ldo, float *stats, hipStream_t st);
 
 // Backward attention on 16-row tiles (attention16_bwd.hip), same convention.
-bool sdpa_bwd16_applies(int N, int dh, bool vec, long long ld, long long ldo, long long ldg);
+bool sdpa_bwd16_applies(int B, int N, int dh, bool vec, long long ld, long long ldo, long long ldg);
 int sdpa_bwd16_launch(const float *q, const float *k, const float *v, long long ld, const float *o, const float *dout,
                       long long ldo, const float *stats, int B, int H, int N, int dh, float scale, int dk_mode,
                       float *dq, float *dk, float *dv, long long ldg, hipStream_t st);
