@@ -9,7 +9,7 @@ from visiontransformer_amd import vitk
 
 vitk.init(0)
 B, H, N, dh = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (256, 12, 197, 64)
-iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 30
 D, M = H * dh, B * N
 g = torch.Generator(device="cuda").manual_seed(1)
 qkv = torch.randn(M, 3 * D, device="cuda", generator=g)
@@ -21,7 +21,7 @@ ws = torch.empty(nb // 4, device="cuda")
 scale = dh ** -0.5
 st = vitk.stream()
 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-tf = tb = 0.0
+tf, tb = [], []
 for it in range(iters + 1):
     e[0].record()
     vitk.call("vitk_sdpa_fwd", qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B, H, N, dh, scale, out, D, stats, st)
@@ -31,8 +31,10 @@ for it in range(iters + 1):
     e[2].record()
     torch.cuda.synchronize()
     if it:  # the first iteration warms up
-        tf += e[0].elapsed_time(e[1])
-        tb += e[1].elapsed_time(e[2])
+        tf.append(e[0].elapsed_time(e[1]))
+        tb.append(e[1].elapsed_time(e[2]))
 flops = 4.0 * B * H * N * N * dh
-print(f"B={B} H={H} N={N} dh={dh}: forward {tf / iters:.3f} ms ({flops / (tf / iters) / 1e9:.1f} TFLOP/s), "
-      f"backward {tb / iters:.3f} ms ({2.5 * flops / (tb / iters) / 1e9:.1f} TFLOP/s)")
+tf.sort(), tb.sort()
+mf, mb = tf[len(tf) // 2], tb[len(tb) // 2]
+print(f"B={B} H={H} N={N} dh={dh}: forward median {mf:.3f} ms (min {tf[0]:.3f}; {flops / mf / 1e9:.1f} TFLOP/s), "
+      f"backward median {mb:.3f} ms (min {tb[0]:.3f}; {2.5 * flops / mb / 1e9:.1f} TFLOP/s)")
