@@ -28,7 +28,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HPW = 4;            // heads per workgroup
+constexpr int HPW = 4;            // heads per workgroup ...
+constexpr int TEAM = 4;           // ... in teams of this many workgroups that share HPW * TEAM heads
 constexpr int KP = 65, VP = 68;   // LDS row pitches of a key tile and of a value tile
 constexpr int SLOT = 32 * VP;     // one head's 32-row tile (either kind)
 constexpr int STAGE = 2 * SLOT;   // two heads may be live in one round
@@ -68,8 +69,23 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int BH = p.B * p.H;
-  const int head0 = blockIdx.x * HPW, nh = min(HPW, BH - head0);
-  const int nblk = (p.N + 15) / 16, items = nh * nblk, rounds = (items + 3) / 4;
+  // Teams.  A head's K and V are re-streamed in every round that touches the head; with every
+  // workgroup on heads of its own, the 96 workgroups resident on an XCD cycle ~10 MB through its
+  // 4 MB L2 between two uses and each round's tiles come from memory again (measured: 1.36 GB read
+  // per launch for 0.47 GB of operands).  So TEAM workgroups that land on the same XCD (workgroups
+  // go to the 8 XCDs round-robin by index) share TEAM * HPW heads and walk their block list
+  // together: in round r workgroup j of the team takes blocks 16 r + 4 j .. + 3, so the team is
+  // on the same one or two heads at the same time and three of its four tile fetches hit in L2.
+  // Placement and pace only matter for speed: results do not depend on either.
+  const int xcd = blockIdx.x % 8, slot_in_xcd = blockIdx.x / 8, tj = slot_in_xcd % TEAM;
+  const int head0 = ((slot_in_xcd / TEAM) * 8 + xcd) * (HPW * TEAM);
+  if (head0 >= BH) return;
+  const int nh = min(HPW * TEAM, BH - head0);
+  const int nblk = (p.N + 15) / 16, items = nh * nblk;
+  constexpr int RSTEP = 4 * TEAM;  // blocks a team takes per round
+  const int first = 4 * tj;        // this workgroup's first block in round 0
+  if (first >= items) return;
+  const int rounds = (items - first + RSTEP - 1) / RSTEP;
   const int srow = threadIdx.x >> 4, scol = (threadIdx.x & 15) * 4;  // this thread's part of a staged tile
   const int tile_bytes = (int)(32 * p.ld * 4), head_bytes = (int)(((long long)(p.N - 1) * p.ld + p.dh) * 4);
   constexpr unsigned kOutside = 0x7fffff00u;  // beyond any descriptor: reads as zero
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
 
   // Position of a block in the workgroup's list of (head, block) items: head index inside the
   // workgroup, block inside the head, the head's index inside its image and its element offset.
-  // Scalar registers, advanced by 4 items per round (no division in the loop).
+  // Scalar registers, advanced by the team's 16 items per round (no division in the loop).
   struct Pos {
     int h, q, hm;
     long long off;
@@ -149,6 +165,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
     }
   };
   Pos lo{0, 0, head0 % p.H, (long long)(head0 / p.H) * p.N * p.ld + (long long)(head0 % p.H) * p.dh};
+  advance(lo, first);
   Pos my = lo;
   advance(my, wave);
   // a round's four blocks span at most two heads (nblk >= 4): the head of the first block and,
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
 
   const float sl2 = p.scale * 1.44269504088896340736f;  // scores are exponentiated in base 2
   f32x4 qf[4], qn[4];
-  if (wave < items) load_query(my.off, my.q, qf);
+  if (first + wave < items) load_query(my.off, my.q, qf);
   {
     long long off2;
     const bool two0 = second_head(lo, &off2);
@@ -172,13 +189,13 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
   int stage = 0;  // ring stage holding the tile about to be used
 
   for (int round = 0; round < rounds; ++round) {
-    const bool active = 4 * round + wave < items;  // wave-uniform; idle waves still stage tiles
+    const bool active = RSTEP * round + first + wave < items;  // wave-uniform; idle waves still stage tiles
     long long hi_off, nhi_off;
     const bool two = second_head(lo, &hi_off);
     const int slot = (active && my.h != lo.h) ? 1 : 0;
     Pos nlo = lo, nmy = my;  // the next round's positions
-    advance(nlo, 4);
-    advance(nmy, 4);
+    advance(nlo, RSTEP);
+    advance(nmy, RSTEP);
     const bool ntwo = second_head(nlo, &nhi_off);
 
     // ---- pass 1: scores, transposed ([key][query]) ----
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
       }
     }
     // the next round's query fragment travels while this round's values are multiplied
-    if (4 * (round + 1) + wave < items) load_query(nmy.off, nmy.q, qn);
+    if (RSTEP * (round + 1) + first + wave < items) load_query(nmy.off, nmy.q, qn);
 
     // ---- pass 2: O^T[d][query] += V^T E^T (unnormalised), divided by the row sum at the end ----
     f32x4 o[4];
@@ -319,7 +336,8 @@ int sdpa_fwd16_launch(const float *q, const float *k, const float *v, long long 
   Fwd16Params p;
   p.q = q; p.k = k; p.v = v; p.ld = ld; p.out = out; p.ldo = ldo; p.stats = stats;
   p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale;
-  const dim3 grid((unsigned)((B * H + HPW - 1) / HPW)), blk(256);
+  const int teams = (B * H + HPW * TEAM - 1) / (HPW * TEAM);
+  const dim3 grid((unsigned)(8 * TEAM * ((teams + 7) / 8))), blk(256);  // (see Teams in the kernel)
   switch ((N + 31) / 32) {
     case 2: hipLaunchKernelGGL((sdpa_fwd16_kernel<2>), grid, blk, 0, st, p); break;
     case 3: hipLaunchKernelGGL((sdpa_fwd16_kernel<3>), grid, blk, 0, st, p); break;
