@@ -232,7 +232,7 @@ def main():
                                                       " HIP stream overlapped with backward)"
                                                       if (world > 1 or args.force_collectives) else ""),
                        "patch_mode": "im2col", "params": int(model.n), "final_loss": round(float(loss), 6),
-                       "last_block": "all tokens (as the reference)" if args.dense_tail or args.dropout > 0 else
+                       "last_block": "all tokens (as the reference)" if args.dense_tail else
                                      "CLS token only after its keys/values (the head reads nothing else; same logits, "
                                      "loss, gradients and updates)"},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2),
@@ -249,10 +249,10 @@ def main():
                          "all_gemm_ms_per_step": round(gemm_ms / args.steps, 3),
                          "step_frac_of_peak": round(value / world * f_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                          "train_gflop_per_image": round(f_img / 1e9, 2),
-                         "train_gflop_per_image_executed": round((f_img if args.dense_tail or args.dropout > 0 else
+                         "train_gflop_per_image_executed": round((f_img if args.dense_tail else
                                                                   executed_train_flops_per_image(cfgd)) / 1e9, 2),
                          "step_frac_of_peak_executed": round(
-                             value / world * (f_img if args.dense_tail or args.dropout > 0 else
+                             value / world * (f_img if args.dense_tail else
                                               executed_train_flops_per_image(cfgd)) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                          "gemm_variants": [{"kernel": r["name"], "launches": r["launches"],
                                             "avg_ms": round(r["ms"] / r["launches"], 4),

@@ -171,6 +171,14 @@ int vitk_dropout_residual_fwd(const float *x, const float *residual, int64_t n, 
 int vitk_dropout_stream_bwd(const float *dy, int64_t n, float rate, uint64_t seed, uint64_t offset, float *dx,
                             vitk_stream_t stream);
 
+/* The same factors applied to a compact [rows][cols] slice of the tensor a dense call would have
+ * covered: element (r, c) takes the factor of flat position r*idx_stride + c (read from `mask`
+ * when it is not NULL, else regenerated from (rate, seed, offset)); y = x*factor (+ residual).
+ * Forward and backward of the dropout around the one token per sequence that the last encoder
+ * block computes, with the masks the dense block would have drawn. */
+int vitk_dropout_rows(const float *x, const float *residual, const float *mask, int64_t rows, int64_t cols,
+                      int64_t idx_stride, float rate, uint64_t seed, uint64_t offset, float *y, vitk_stream_t stream);
+
 /* ---- element-wise helpers (Tensor::operator+, src/core/Tensor.cpp:316-351; fill :128-137) ----- */
 int vitk_add_f32(const float *a, const float *b, int64_t n, float *out, vitk_stream_t stream);
 int vitk_add3_f32(const float *a, const float *b, const float *c, int64_t n, float *out, vitk_stream_t stream);

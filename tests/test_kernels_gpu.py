@@ -581,6 +581,27 @@ def test_gemm_every_slab_count_through_prologue_unrolled_loop_and_tail(K, ta, tb
             K.gemm(dev(a), dev(b), c, M, N, Kd, trans_a=bool(ta), trans_b=bool(tb))
             close(host(c), ref_gemm(a, b, ta, tb), 1e-5)
 
+@pytest.mark.parametrize("B,N,D", [(5, 7, 12), (3, 197, 64), (4, 5, 10)])
+def test_dropout_rows_takes_the_factors_of_the_dense_call(K, B, N, D):
+    """vitk_dropout_rows on the first token of every sequence = those rows of vitk_dropout_residual_fwd
+    over the whole {B,N,D} tensor at the same stream position, with and without a recorded mask."""
+    rate, seed, off = 0.3, 0x1234567, 77
+    x, res = V.rng_normal(1, B * N * D), V.rng_normal(2, B * N * D)
+    dense, mask = empty(B * N * D), empty(B * N * D)
+    K.call("vitk_dropout_residual_fwd", dev(x), dev(res), B * N * D, rate, seed, off, dense, mask, K.stream())
+    want = host(dense).reshape(B, N * D)[:, :D]
+    x0 = np.ascontiguousarray(x.reshape(B, N * D)[:, :D])
+    r0 = np.ascontiguousarray(res.reshape(B, N * D)[:, :D])
+    got = empty(B, D)
+    K.call("vitk_dropout_rows", dev(x0), dev(r0), None, B, D, N * D, rate, seed, off, got, K.stream())
+    np.testing.assert_array_equal(host(got), want)
+    K.call("vitk_dropout_rows", dev(x0), dev(r0), mask, B, D, N * D, rate, 0, 0, got, K.stream())
+    np.testing.assert_array_equal(host(got), want)
+    # backward form: no residual
+    K.call("vitk_dropout_rows", dev(x0), None, None, B, D, N * D, rate, seed, off, got, K.stream())
+    np.testing.assert_array_equal(host(got), x0 * host(mask).reshape(B, N * D)[:, :D])
+
+
 def test_gather_rows_assembles_a_shuffled_batch(K):
     src = V.rng_normal(3, 50, 37)
     idx = np.random.default_rng(4).permutation(50)[:21].astype(np.int32)

@@ -179,12 +179,14 @@ def test_model_activations_gradients_and_steps_match_reference(H, name, fused):
     V.check_digest(m.get_params(), shapes, g["p_sums"], g["p_norms"], g["p_samples"], 5e-5, "param after Adam")
 
 
-@pytest.mark.parametrize("name,B", [("C1", 16), ("C2", 8), ("C3", 2)])
-def test_first_token_tail_equals_the_dense_computation(H, name, B):
+@pytest.mark.parametrize("name,B,rate", [("C1", 16, 0.0), ("C2", 8, 0.0), ("C3", 2, 0.0), ("C1", 16, 0.2), ("C3", 2, 0.1)])
+def test_first_token_tail_equals_the_dense_computation(H, name, B, rate):
     """The last encoder block and the final norm restricted to the CLS token (the default) against
     the same model with every token computed: logits (training and inference), loss, every
-    parameter gradient, and the parameters after two Adam steps."""
-    cfgd = V.CONFIGS[name]
+    parameter gradient, and the parameters after two Adam steps.  With dropout active both forms
+    start from the same stream position and must draw the same masks (the CLS-only block takes
+    the factors of its rows of the full tensors and moves the stream on by the full tensors)."""
+    cfgd = dict(V.CONFIGS[name], dropout_rate=rate)
     ocfg = V.Cfg.make(**cfgd)
     prm = V.init_params(ocfg, 33)
     K = ocfg.num_classes
@@ -193,6 +195,7 @@ def test_first_token_tail_equals_the_dense_computation(H, name, B):
     runs = {}
     for tail in (True, False):
         H.set_first_token_tail(tail)
+        H.set_dropout_state(20260101, 0)
         try:
             m = H.Model(hcfg(H, cfgd))
             m.set_params(prm)
@@ -206,10 +209,11 @@ def test_first_token_tail_equals_the_dense_computation(H, name, B):
             g = m.get_grads()
             for s in range(2):
                 t.train_step(xs[s], ys[s], 1e-3)
-            runs[tail] = (ev, tr, loss, ok, g, m.get_params())
+            runs[tail] = (ev, tr, loss, ok, g, m.get_params(), H.dropout_state())
         finally:
             H.set_first_token_tail(True)
     a, b = runs[True], runs[False]
+    assert a[6] == b[6]  # both forms moved the dropout stream by the same amount
     close(a[0], b[0], 2e-5, "inference logits")
     close(a[1], b[1], 2e-5, "training logits")
     assert abs(a[2] - b[2]) <= 1e-5 * abs(b[2]) and a[3] == b[3]

@@ -194,6 +194,31 @@ __global__ void dropout_bwd_stream_kernel(const float *__restrict__ dy, long lon
   }
 }
 
+// The same factors for a compact [rows][cols] slice of a larger tensor: element (r, c) takes the
+// factor of flat position r * idx_stride + c of that tensor (from `mask` when given, else from the
+// stream).  y = x * m (+ residual).  Small by construction (one token per sequence): one element
+// per thread.
+__global__ void dropout_rows_kernel(const float *__restrict__ x, const float *__restrict__ residual,
+                                    const float *__restrict__ mask, long long rows, long long cols, long long idx_stride,
+                                    float rate, float scale, unsigned long long seed, unsigned long long offset,
+                                    float *__restrict__ y) {
+  const long long total = rows * cols, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long flat = (i / cols) * idx_stride + i % cols;
+    float f;
+    if (mask != nullptr) {
+      f = mask[flat];
+    } else {
+      float m[4];
+      dropout_factors(offset + (unsigned long long)(flat >> 2), seed, rate, scale, m);
+      const int w = (int)(flat & 3);
+      f = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
+    }
+    const float o = x[i] * f;
+    y[i] = residual != nullptr ? residual[i] + o : o;
+  }
+}
+
 struct GeluF { __device__ float operator()(float v) const { return vitk::gelu_fwd(v); } };
 struct GeluB { __device__ float operator()(float x, float dy) const { return vitk::gelu_grad(x) * dy; } };
 struct AddF { __device__ float operator()(float a, float b) const { return a + b; } };
@@ -252,6 +277,18 @@ int vitk_dropout_stream_bwd(const float *dy, int64_t n, float rate, uint64_t see
                      vitk::as_stream(stream), dy, (long long)n, rate, scale, (unsigned long long)seed,
                      (unsigned long long)offset, dx, vec);
   return vitk::check_launch("vitk_dropout_stream_bwd");
+}
+
+int vitk_dropout_rows(const float *x, const float *residual, const float *mask, int64_t rows, int64_t cols,
+                      int64_t idx_stride, float rate, uint64_t seed, uint64_t offset, float *y, vitk_stream_t stream) {
+  VITK_REQUIRE(rows >= 0 && cols >= 0 && idx_stride >= cols, "vitk_dropout_rows: bad shape");
+  if (rows == 0 || cols == 0) return 0;
+  VITK_REQUIRE(x && y, "vitk_dropout_rows: null pointer");
+  VITK_REQUIRE(rate >= 0.0f && rate < 1.0f, "vitk_dropout_rows: rate %g outside [0,1)", (double)rate);
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3(vitk::grid_for(rows * cols, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                     x, residual, mask, (long long)rows, (long long)cols, (long long)idx_stride, rate,
+                     1.0f / (1.0f - rate), (unsigned long long)seed, (unsigned long long)offset, y);
+  return vitk::check_launch("vitk_dropout_rows");
 }
 
 int vitk_dropout_bwd(const float *dy, const float *mask, int64_t n, float *dx, vitk_stream_t stream) {

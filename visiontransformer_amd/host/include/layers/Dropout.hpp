@@ -16,6 +16,11 @@ public:
   Tensor backward(const Tensor &outputGradient) override;
   // residual + dropout(input) in one pass (the skip connections of the encoder block)
   Tensor forwardAdd(const Tensor &input, const Tensor &residual, bool isTraining);
+  // The same for ONE token per sequence: input / residual are {B,1,D}, and the factors are those a
+  // call over the whole {B,tokens,D} tensor would have given row 0 of every sequence (the stream
+  // advances as for that call), so a block that computes only the CLS token draws the masks of
+  // the block that computes every token.  residual may be null.
+  Tensor forwardAddFirstToken(const Tensor &input, const Tensor *residual, size_t tokens, bool isTraining);
   std::string getName() const override { return "Dropout"; }
   bool active(bool isTraining) const { return isTraining && rate != 0.0f; }
 
@@ -25,6 +30,7 @@ private:
   // stream position and extent of the last training-mode forward (count 0: none)
   uint64_t seed = 0, offset = 0;
   size_t count = 0;
+  size_t rowStride = 0, rows = 0, cols = 0;  // rowStride != 0: the last forward was forwardAddFirstToken
   // recorded factors used by the last forward instead of the stream (vit::set_dropout_replay)
   const float *replayed = nullptr;
 };

@@ -23,7 +23,9 @@ public:
   std::string getName() const override { return "FeedForward"; }
 
   // forward with `residual + .` fused into dense2's epilogue when dropout is inactive
-  Tensor forwardFused(const Tensor &input, bool isTraining, const Tensor *residual);
+  // firstTokenOf != 0: input is {B,1,D}, the first token of sequences of that many tokens; the
+  // dropout then applies the factors of those rows of the whole {B,tokens,D} tensor
+  Tensor forwardFused(const Tensor &input, bool isTraining, const Tensor *residual, size_t firstTokenOf = 0);
 
 private:
   Dense dense1;

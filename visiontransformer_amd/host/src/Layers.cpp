@@ -199,6 +199,7 @@ Tensor Dropout::forward(const Tensor &input, bool isTraining) {
   if (!input.isContiguous()) throw std::runtime_error("Dropout::forward actualmente solo soporta tensores contiguos.");
   Tensor y = Tensor::deviceEmpty(input.getShape());
   count = input.getSize();
+  rowStride = 0;
   if ((replayed = vit::dropout_replay_take(count)) != nullptr) {
     vit::check(vitk_dropout_bwd(input.deviceData(), replayed, (int64_t)count, y.deviceDataOverwrite(), S()),
                "vitk_dropout_bwd");
@@ -220,6 +221,7 @@ Tensor Dropout::forwardAdd(const Tensor &input, const Tensor &residual, bool isT
     throw std::runtime_error("Dropout::forwardAdd espera dos tensores contiguos del mismo tamano.");
   Tensor y = Tensor::deviceEmpty(input.getShape());
   count = input.getSize();
+  rowStride = 0;
   if ((replayed = vit::dropout_replay_take(count)) != nullptr) {
     vit::check(vitk_dropout_bwd(input.deviceData(), replayed, (int64_t)count, y.deviceDataOverwrite(), S()),
                "vitk_dropout_bwd");
@@ -234,8 +236,37 @@ Tensor Dropout::forwardAdd(const Tensor &input, const Tensor &residual, bool isT
   return y;
 }
 
+Tensor Dropout::forwardAddFirstToken(const Tensor &input, const Tensor *residual, size_t tokens, bool isTraining) {
+  if (!isTraining || rate == 0.0f) {
+    count = 0;
+    return residual ? *residual + input : input;
+  }
+  const auto &sh = input.getShape();
+  if (!input.isContiguous() || sh.size() != 3 || sh[1] != 1 || (residual && (!residual->isContiguous() || residual->getSize() != input.getSize())))
+    throw std::runtime_error("Dropout::forwardAddFirstToken espera tensores contiguos {B,1,D}.");
+  rows = sh[0], cols = sh[2], rowStride = tokens * cols;
+  count = input.getSize();
+  Tensor y = Tensor::deviceEmpty(sh);
+  // the stream (or the recorded masks) moves on by the whole {B,tokens,D} tensor
+  replayed = vit::dropout_replay_take(rows * rowStride);
+  if (!replayed) vit::dropout_stream(rows * rowStride, &seed, &offset);
+  vit::check(vitk_dropout_rows(input.deviceData(), residual ? residual->deviceData() : nullptr, replayed, (int64_t)rows,
+                               (int64_t)cols, (int64_t)rowStride, rate, seed, offset, y.deviceDataOverwrite(), S()),
+             "vitk_dropout_rows");
+  return y;
+}
+
 Tensor Dropout::backward(const Tensor &outputGradient) {
   if (count == 0) return outputGradient;  // forward ran in inference mode or with rate 0
+  if (rowStride != 0) {
+    if (!outputGradient.isContiguous() || outputGradient.getSize() != count)
+      throw std::runtime_error("Dropout::backward espera un gradiente contiguo con la forma de la entrada.");
+    Tensor dx = Tensor::deviceEmpty(outputGradient.getShape());
+    vit::check(vitk_dropout_rows(outputGradient.deviceData(), nullptr, replayed, (int64_t)rows, (int64_t)cols,
+                                 (int64_t)rowStride, rate, seed, offset, dx.deviceDataOverwrite(), S()),
+               "vitk_dropout_rows");
+    return dx;
+  }
   if (!outputGradient.isContiguous() || outputGradient.getSize() != count)
     throw std::runtime_error("Dropout::backward espera un gradiente contiguo con la forma de la entrada.");
   Tensor dx = Tensor::deviceEmpty(outputGradient.getShape());
@@ -261,11 +292,12 @@ FeedForward::FeedForward(size_t embedding_dim, size_t hidden_dim, float dropout_
 
 Tensor FeedForward::forward(const Tensor &input, bool isTraining) { return forwardFused(input, isTraining, nullptr); }
 
-Tensor FeedForward::forwardFused(const Tensor &input, bool isTraining, const Tensor *residual) {
+Tensor FeedForward::forwardFused(const Tensor &input, bool isTraining, const Tensor *residual, size_t firstTokenOf) {
   // dense1 + GELU in one kernel; the pre-activation is kept for backward
   Tensor h = dense1.forwardFused(input, isTraining, VITK_ACT_GELU_FWD, isTraining ? &preActivation : nullptr, nullptr);
   const bool drop = dropout.active(isTraining);
   Tensor y = dense2.forwardFused(h, isTraining, VITK_ACT_NONE, nullptr, drop ? nullptr : residual);
+  if (drop && firstTokenOf != 0) return dropout.forwardAddFirstToken(y, residual, firstTokenOf, isTraining);
   if (drop) y = residual ? dropout.forwardAdd(y, *residual, isTraining) : dropout.forward(y, isTraining);
   return y;
 }

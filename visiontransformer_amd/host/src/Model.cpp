@@ -46,8 +46,8 @@ Tensor TransformerEncoderBlock::backward(const Tensor &outputGradient) {
 }
 
 bool TransformerEncoderBlock::firstTokenSupported(size_t tokens, bool isTraining) const {
-  // (with dropout active the masks are indexed by position in the full {B,N,D} tensors: dense path)
-  return !attention_dropout.active(isTraining) && attention.firstTokenSupported(tokens);
+  (void)isTraining;  // (active dropout: the first token takes the factors of its rows of the full {B,N,D} masks)
+  return attention.firstTokenSupported(tokens);
 }
 
 Tensor TransformerEncoderBlock::forwardFirstToken(const Tensor &input, bool isTraining) {
@@ -59,15 +59,21 @@ Tensor TransformerEncoderBlock::forwardFirstToken(const Tensor &input, bool isTr
   vit::check(vitk_copy2d_f32(in.deviceData(), (int64_t)(N * D), in0.deviceDataOverwrite(), (int64_t)D, (int64_t)B,
                              (int64_t)D, S()),
              "vitk_copy2d_f32");
-  Tensor residual1 = attention.forwardFirstToken(x, isTraining, &in0);  // {B,1,D}
+  Tensor residual1;  // {B,1,D}
+  if (attention_dropout.active(isTraining)) {
+    Tensor a = attention.forwardFirstToken(x, isTraining, nullptr);
+    residual1 = attention_dropout.forwardAddFirstToken(a, &in0, N, isTraining);
+  } else {
+    residual1 = attention.forwardFirstToken(x, isTraining, &in0);  // add fused into out_proj's epilogue
+  }
   Tensor y = norm2.forward(residual1, isTraining);
-  return ffn.forwardFused(y, isTraining, &residual1);
+  return ffn.forwardFused(y, isTraining, &residual1, N);
 }
 
 Tensor TransformerEncoderBlock::backwardFirstToken(const Tensor &outputGradient) {
   Tensor g = ffn.backward(outputGradient);                   // {B,1,D}
   Tensor grad1 = norm2.backwardFused(g, &outputGradient);    // d residual1 of the first token
-  Tensor gm = attention.backwardFirstToken(grad1);           // dense {B,N,D}: keys / values of every token
+  Tensor gm = attention.backwardFirstToken(attention_dropout.backward(grad1));  // dense {B,N,D}: keys / values of every token
   Tensor dx = norm1.backwardFused(gm, nullptr);
   const auto &s = dx.getShape();
   // skip connection of the first token: d input[:,0,:] += d residual1

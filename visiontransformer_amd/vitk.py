@@ -63,6 +63,7 @@ SIGNATURES = {
     "vitk_dropout_bwd": (C.c_int, [_p, _p, _i64, _p, _p]),
     "vitk_dropout_residual_fwd": (C.c_int, [_p, _p, _i64, _f, C.c_uint64, C.c_uint64, _p, _p, _p]),
     "vitk_dropout_stream_bwd": (C.c_int, [_p, _i64, _f, C.c_uint64, C.c_uint64, _p, _p]),
+    "vitk_dropout_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _f, C.c_uint64, C.c_uint64, _p, _p]),
     "vitk_add_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "vitk_add3_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p]),
     "vitk_scale_f32": (C.c_int, [_p, _f, _i64, _p, _p]),
