@@ -102,12 +102,17 @@ __global__ __launch_bounds__(TPB) void sdpa_row_fwd_kernel(const RowParams p, in
 //   dS = p (dP - dsum) * scale;  dV[key] = p[key] dO;  dK[key] = dS[key] q;  dQ = sum_key dS[key] K[key].
 // dk_mode VITK_DK_REFERENCE stores the key gradient the way the reference re-reads its [dh][N]
 // buffer as [N][dh] (src/layers/MultiHeadAttention.cpp:207-222): element (d, key) at flat d*N + key.
+// Sixteen lanes share a key row (lane j holds columns 4j .. 4j+3), so every K / V read and every
+// dK / dV write of a wave covers whole 256-byte rows; the sixteen lane groups of the workgroup
+// take keys g, g+16, ...
 __global__ __launch_bounds__(TPB) void sdpa_row_bwd_kernel(const RowParams p, int vec) {
-  __shared__ float qs[MAX_DH], gs[MAX_DH], dsv[TPB], red[TPB / 64], part[TPB / 64][MAX_DH];
+  __shared__ float qs[MAX_DH], gs[MAX_DH], dsv[TPB], red[TPB / 64], part[TPB / 16][MAX_DH];
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, t = threadIdx.x;
   const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
   const long long ghead = (long long)b * p.N * p.ldg + (long long)h * p.dh;
   float od = 0.f;
+  if (t < MAX_DH) qs[t] = 0.f, gs[t] = 0.f;  // (columns past dh stay zero: the quads below read them)
+  __syncthreads();
   if (t < p.dh) {
     qs[t] = p.q[(long long)b * p.ldq + (long long)h * p.dh + t];
     gs[t] = p.dout[(long long)b * p.ldo + (long long)h * p.dh + t];
@@ -115,47 +120,79 @@ __global__ __launch_bounds__(TPB) void sdpa_row_bwd_kernel(const RowParams p, in
   }
   const float dsum = block_reduce(od, false, red);  // (its barriers also publish qs / gs)
   const float m = p.stats[2 * (long long)bh], inv = 1.0f / p.stats[2 * (long long)bh + 1];
-  const bool key_ok = t < p.N;
-  float pr = 0.f, ds = 0.f;
-  if (key_ok) {
-    const float s = key_dot(p.k + head + (long long)t * p.ld, qs, p.dh, vec) * p.scale;
-    const float dp = key_dot(p.v + head + (long long)t * p.ld, gs, p.dh, vec);
-    pr = __expf(s - m) * inv;
-    ds = (pr * (dp - dsum)) * p.scale;
-    float *dvrow = p.dv + ghead + (long long)t * p.ldg;
-    if (vec) {
-      for (int d = 0; d < p.dh; d += 4)
-        *reinterpret_cast<float4 *>(dvrow + d) = make_float4(pr * gs[d], pr * gs[d + 1], pr * gs[d + 2], pr * gs[d + 3]);
-    } else {
-      for (int d = 0; d < p.dh; ++d) dvrow[d] = pr * gs[d];
-    }
-    if (p.dk_mode == VITK_DK_EXACT) {
-      float *dkrow = p.dk + ghead + (long long)t * p.ldg;
+  const int grp = t >> 4, j = t & 15, d0 = 4 * j;
+  const bool col_ok = d0 < p.dh;
+  float q4[4], g4[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) q4[e] = qs[d0 + e], g4[e] = gs[d0 + e];
+  for (int key0 = 0; key0 < p.N; key0 += TPB / 16) {
+    const int key = key0 + grp;
+    const bool ok = key < p.N && col_ok;
+    float k4[4] = {0.f, 0.f, 0.f, 0.f}, v4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const float *krow = p.k + head + (long long)key * p.ld + d0, *vrow = p.v + head + (long long)key * p.ld + d0;
       if (vec) {
-        for (int d = 0; d < p.dh; d += 4)
-          *reinterpret_cast<float4 *>(dkrow + d) = make_float4(ds * qs[d], ds * qs[d + 1], ds * qs[d + 2], ds * qs[d + 3]);
+        const float4 a = *reinterpret_cast<const float4 *>(krow), c = *reinterpret_cast<const float4 *>(vrow);
+        k4[0] = a.x, k4[1] = a.y, k4[2] = a.z, k4[3] = a.w;
+        v4[0] = c.x, v4[1] = c.y, v4[2] = c.z, v4[3] = c.w;
       } else {
-        for (int d = 0; d < p.dh; ++d) dkrow[d] = ds * qs[d];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (d0 + e < p.dh) k4[e] = krow[e], v4[e] = vrow[e];
       }
     }
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += k4[e] * q4[e], dp += v4[e] * g4[e];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 16), dp += __shfl_xor(dp, w, 16);
+    const float pr = key < p.N ? __expf(s * p.scale - m) * inv : 0.f;
+    const float ds = (pr * (dp - dsum)) * p.scale;
+    if (j == 0 && key < TPB) dsv[key] = key < p.N ? ds : 0.f;
+    if (ok) {
+      float *dvrow = p.dv + ghead + (long long)key * p.ldg + d0;
+      if (vec) {
+        *reinterpret_cast<float4 *>(dvrow) = make_float4(pr * g4[0], pr * g4[1], pr * g4[2], pr * g4[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (d0 + e < p.dh) dvrow[e] = pr * g4[e];
+      }
+      if (p.dk_mode == VITK_DK_EXACT) {
+        float *dkrow = p.dk + ghead + (long long)key * p.ldg + d0;
+        if (vec) {
+          *reinterpret_cast<float4 *>(dkrow) = make_float4(ds * q4[0], ds * q4[1], ds * q4[2], ds * q4[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (d0 + e < p.dh) dkrow[e] = ds * q4[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += ds * k4[e];
   }
-  dsv[t] = ds;
-  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[grp][d0 + e] = acc[e];
+  __syncthreads();  // dsv and the per-group dQ partials are complete
   if (p.dk_mode != VITK_DK_EXACT) {
-    // T[d][key] = q[d] dS[key] lands at flat index f = d*N + key of the head's [N][dh] block
+    // T[d][key] = q[d] dS[key] lands at flat index f = d*N + key of the head's [N][dh] block; walk
+    // the block in memory order (row f / dh, column f % dh) so that the writes are coalesced
     const int total = p.N * p.dh;
-    for (int f = t; f < total; f += TPB) p.dk[ghead + (long long)(f / p.dh) * p.ldg + f % p.dh] = qs[f / p.N] * dsv[f % p.N];
+    const float inv_n = 1.0f / (float)p.N;
+    for (int f = t; f < total; f += TPB) {
+      int d = (int)(((float)f + 0.5f) * inv_n);  // f / N, corrected below (f < 2^24)
+      if (d * p.N > f) --d;
+      else if ((d + 1) * p.N <= f) ++d;
+      const int key = f - d * p.N;
+      const int row = p.dh == 64 ? f >> 6 : f / p.dh, col = p.dh == 64 ? f & 63 : f % p.dh;
+      p.dk[ghead + (long long)row * p.ldg + col] = qs[d] * dsv[key];
+    }
   }
-  const int lane = t & 63, wave = t >> 6;
-  float acc = 0.f;
-  if (lane < p.dh)
-    for (int key = wave; key < p.N; key += TPB / 64) acc += dsv[key] * p.k[head + (long long)key * p.ld + lane];
-  part[wave][lane] = acc;
-  __syncthreads();
   if (t < p.dh) {
     float r = 0.f;
 #pragma unroll
-    for (int w = 0; w < TPB / 64; ++w) r += part[w][t];
+    for (int w = 0; w < TPB / 16; ++w) r += part[w][t];
     p.dq[(long long)b * p.lddq + (long long)h * p.dh + t] = r;
   }
 }

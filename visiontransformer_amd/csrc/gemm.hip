@@ -644,6 +644,35 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int S, int M,
   }
 }
 
+// The same sum for one unbatched, unpitched, 16-byte-aligned result (every weight gradient of the
+// model): a float4 per thread and no index arithmetic -- the kernel is pure streaming.
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float *__restrict__ ws, int S, long long mn4,
+                                                                float *__restrict__ C, int matrix_blocks, int N,
+                                                                const float *__restrict__ colsum_ws,
+                                                                float *__restrict__ colsum) {
+  if ((int)blockIdx.x >= matrix_blocks) {  // trailing workgroups: the column sums of B, partials [S][N]
+    const int n = ((int)blockIdx.x - matrix_blocks) * 256 + threadIdx.x;
+    if (n < N) {
+      float t = 0.f;
+      for (int k = 0; k < S; ++k) t += colsum_ws[(long long)k * N + n];
+      colsum[n] = t;
+    }
+    return;
+  }
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= mn4) return;
+  const f32x4 *w = reinterpret_cast<const f32x4 *>(ws) + i;
+  f32x4 s = w[0];
+  int k = 1;
+  for (; k + 3 < S; k += 4) {  // four loads in flight; the additions stay in split order
+    const f32x4 a = w[(long long)k * mn4], b = w[(long long)(k + 1) * mn4], c = w[(long long)(k + 2) * mn4],
+                d = w[(long long)(k + 3) * mn4];
+    s = (((s + a) + b) + c) + d;
+  }
+  for (; k < S; ++k) s += w[(long long)k * mn4];
+  reinterpret_cast<f32x4 *>(C)[i] = s;
+}
+
 #ifdef VITK_GEMM_STAMPS
 unsigned long long *g_stamps = nullptr;
 #endif
@@ -900,6 +929,11 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   if (vitk::check_launch("vitk_gemm_f32")) return 1;
   if (pl.split_k > 1) {
     const long long total = (long long)pl.batch * a->M * a->N;
+    if (pl.batch == 1 && a->ldc == a->N && total % 4 == 0 && vitk::aligned16(a->C) && vitk::aligned16(a->workspace)) {
+      const int mb = (int)((total / 4 + 255) / 256), cb = p.colsum != nullptr ? (a->N + 255) / 256 : 0;
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)(mb + cb)), dim3(256), 0, st, a->workspace, pl.split_k,
+                         total / 4, a->C, mb, a->N, p.colsum_ws, p.colsum);
+    } else
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(vitk::grid_for(total, 256)), dim3(256), 0, st, a->workspace,
                        pl.split_k, a->M, a->N, a->C, a->ldc, p.batch_inner, p.sc_o, p.sc_i, total, p.colsum_ws, p.colsum);
     if (vitk::check_launch("vitk_gemm_f32/splitk_reduce")) return 1;
