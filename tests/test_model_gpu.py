@@ -545,39 +545,44 @@ VIT_B16 = dict(image_size=224, patch_size=16, in_channels=3, num_classes=1000, e
                num_layers=12, mlp_hidden_dim=3072)
 
 
-def test_vit_b16_full_batch_two_attention_paths_agree_and_step_is_reproducible(H):
-    """ViT-B/16 at the benchmark's batch of 256 (too large for the CPU oracle, which needs hours
-    per step): the properties that do not depend on size.  (1) The two independent attention
-    implementations -- fused kernels vs batched contractions + row softmax -- give the same loss
-    and the same gradient for every parameter tensor (1e-4 of the tensor's max magnitude).
-    (2) Random-init loss is ln(1000) + var(logit)/2 (logits of a N(0, 0.02) head on unit-variance
-    normalised features: var = 768 * 0.02^2).  (3) Repeating the step
-    reproduces the gradients bit for bit (fixed-order split-K, column sums and reductions; no
-    atomics anywhere on the path).  (4) One Adam step moves every parameter tensor."""
+@pytest.mark.parametrize("name,B", [("C5", 256), ("C4", 256), ("C3", 256), ("C2", 512), ("C1", 128)])
+def test_full_batch_paths_agree_and_step_is_reproducible(H, name, B):
+    """Every BASELINE configuration at its full batch (ViT-B/16, ViT-S/16, ViT-Ti/16 at 256, the
+    blood-cell model at 512, the MNIST model at 128 -- too large for the CPU oracle, which needs
+    hours per ViT-B step): the properties that do not depend on size.  (1) Independent
+    implementations give the same loss and the same gradient for every parameter tensor (1e-4 of
+    the tensor's max magnitude): fused attention kernels vs batched contractions + row softmax,
+    and the CLS-only last block vs the dense one.  (2) Random-init loss is ln(K) + var(logit)/2
+    (logits of a N(0, 0.02) head on unit-variance normalised features: var = D * 0.02^2).
+    (3) Repeating the step reproduces the gradients bit for bit (fixed-order split-K, column sums
+    and reductions; no atomics anywhere on the path).  (4) One Adam step moves every tensor."""
     from visiontransformer_amd import vitk
-    B = 256
-    cfg = hcfg(H, VIT_B16)
+    cfgd = V.CONFIGS[name]
+    cfg = hcfg(H, cfgd)
+    K, D = cfgd["num_classes"], cfgd["embedding_dim"]
     g = torch.Generator(device="cuda").manual_seed(7)
-    x = torch.randn(B, 3, 224, 224, device="cuda", generator=g)
-    labels = torch.randint(0, 1000, (B,), device="cuda", generator=g)
-    y = torch.nn.functional.one_hot(labels, 1000).to(torch.float32).contiguous()
+    x = torch.randn(B, cfgd["in_channels"], cfgd["image_size"], cfgd["image_size"], device="cuda", generator=g)
+    labels = torch.randint(0, K, (B,), device="cuda", generator=g)
+    y = torch.nn.functional.one_hot(labels, K).to(torch.float32).contiguous()
 
-    def run(fused):
+    def run(fused, tail=True):
         H.set_fused_attention(fused)
+        H.set_first_token_tail(tail)
         try:
             H.seed(99)
             m = H.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
+            t = H.Trainer(m, weight_decay=1e-4)
+            t.step_forward(x, y)
+            for s in range(t.num_stages):
+                t.backward_stage(s)
+            loss, _ = t.result()
+            return m, t, loss, m.get_grads()
         finally:
             H.set_fused_attention(True)
-        t = H.Trainer(m, weight_decay=1e-4)
-        t.step_forward(x, y)
-        for s in range(t.num_stages):
-            t.backward_stage(s)
-        loss, _ = t.result()
-        return m, t, loss, m.get_grads()
+            H.set_first_token_tail(True)
 
     m1, t1, loss1, g1 = run(True)
-    assert abs(loss1 - (np.log(1000.0) + 0.5 * 768 * 0.02 ** 2)) < 0.05, loss1
+    assert abs(loss1 - (np.log(float(K)) + 0.5 * D * 0.02 ** 2)) < 0.05, loss1
     # (3) same step again on the same model: bit-identical gradients
     t1.step_forward(x, y)
     for s in range(t1.num_stages):
@@ -595,15 +600,18 @@ def test_vit_b16_full_batch_two_attention_paths_agree_and_step_is_reproducible(H
         off += k
     del m1, t1
     torch.cuda.empty_cache()
-    # (1) the unfused path, same seed => same initial weights
-    m2, t2, loss2, g2 = run(False)
-    assert abs(loss2 - loss1) <= 1e-5 * abs(loss1), (loss1, loss2)
-    off = 0
-    for i, shp in enumerate(shapes):
-        k = int(np.prod(shp))
-        e = V.max_relerr(g1[off:off + k], g2[off:off + k], floor=1e-7)
-        assert e <= 1e-4, f"grad tensor {i} {shp}: fused vs unfused attention {e:.3e}"
-        off += k
+    # (1) the other implementations, same seed => same initial weights
+    for what, kw in (("unfused attention", dict(fused=False)), ("dense last block", dict(fused=True, tail=False))):
+        m2, t2, loss2, g2 = run(**kw)
+        assert abs(loss2 - loss1) <= 1e-5 * abs(loss1), (what, loss1, loss2)
+        off = 0
+        for i, shp in enumerate(shapes):
+            k = int(np.prod(shp))
+            e = V.max_relerr(g1[off:off + k], g2[off:off + k], floor=1e-7)
+            assert e <= 1e-4, f"grad tensor {i} {shp}: default path vs {what} {e:.3e}"
+            off += k
+        del m2, t2
+        torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------ resumable training state
