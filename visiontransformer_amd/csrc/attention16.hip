@@ -3,9 +3,10 @@
 //
 // Why a second forward kernel.  ViT sequences are 197 tokens: in 32-row tiles that is 7 x 32 = 224
 // rows (+29 % score area) and 7 query tiles for a workgroup of 4 waves (one wave in eight idle).
-// In 16-row tiles it is 13 x 16 = 208 rows, and an odd tile count is evened out by letting a
-// workgroup own FOUR heads: their 4 x 13 = 52 query blocks are dealt to the 4 waves round by
-// round, 13 rounds with every wave busy in every one.
+// In 16-row tiles it is 13 x 16 = 208 rows, and an odd tile count is evened out by dealing the
+// query blocks of SEVERAL heads to the waves round by round: a team of four workgroups owns 16
+// heads = 208 blocks = 13 rounds of 16 blocks, 4 consecutive ones per workgroup (one per wave),
+// with every wave busy in every round (see Teams in the kernel for why four workgroups share).
 //
 // One round = each wave computes one block of 16 queries of "its" head against all keys:
 //   pass 1  S^T[key][query] = K Q^T over all key tiles  (NKT x 4 accumulator registers per lane),
@@ -13,8 +14,8 @@
 //   pass 2  O^T[d][query] += V^T P^T with the probabilities fed back as operand B, register by
 //           register (accumulator register r of lane (c, g) is row 4g + r = the contraction index
 //           the next product wants from lane group g).
-// The four blocks of a round belong to at most two heads (13 >= 4); K and V tiles of those heads
-// stream through a two-stage LDS ring, 32 keys per stage, loaded by all 256 threads.  The stream
+// The four blocks of a workgroup's round belong to at most two heads (13 >= 4); K and V tiles of
+// those heads stream through a two-stage LDS ring, 32 keys per stage, loaded by all 256 threads.  The stream
 // runs on across rounds, so a wave never waits for a round's first tile.
 //
 // Lane (c = lane & 15, g = lane >> 4) of v_mfma_f32_16x16x4_f32 supplies A[i = c][k = g] and
