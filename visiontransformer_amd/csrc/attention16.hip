@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
     store_tile(0, false, two0);
   }
   __syncthreads();
-  int stage = 0;  // ring stage holding the tile about to be used
+  // (a round is 2 * NS steps, an even number: step t of a round always uses ring stage t & 1, so
+  // every LDS address below is a per-round register plus an instruction immediate)
 
   for (int round = 0; round < rounds; ++round) {
     const bool active = RSTEP * round + first + wave < items;  // wave-uniform; idle waves still stage tiles
@@ -199,6 +200,8 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
     advance(nmy, RSTEP);
     const bool ntwo = second_head(nlo, &nhi_off);
 
+    const float *const kbase = ring + slot * SLOT + c * KP + 16 * g, *const vbase = ring + slot * SLOT + (4 * g) * VP + c;
+
     // ---- pass 1: scores, transposed ([key][query]) ----
     f32x4 s[NKT];  // (the last one stays zero when the last stage holds one tile)
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
         const bool last_k = t + 1 == NS;  // next in the stream: key tile t+1, or value tile 0
         load_tile(last_k ? p.v : p.k, lo.off, hi_off, two, last_k ? 0 : t + 1);
         if (active) {
-          const float *ks = ring + stage * STAGE + slot * SLOT + c * KP + 16 * g;
+          const float *ks = kbase + (t & 1) * STAGE;
           float ka[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) ka[i] = ks[i];
@@ -228,8 +231,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
               s[2 * t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i], qf[i / 4][i % 4], s[2 * t], 0, 0, 0);
           }
         }
-        stage ^= 1;
-        store_tile(stage, last_k, two);
+        store_tile((t + 1) & 1, last_k, two);
         __syncthreads();
       }
     }
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
         if (!last_v) load_tile(p.v, lo.off, hi_off, two, t + 1);
         else if (more) load_tile(p.k, nlo.off, nhi_off, ntwo, 0);
         if (active) {
-          const float *vs = ring + stage * STAGE + slot * SLOT + (4 * g) * VP + c;
+          const float *vs = vbase + ((NS + t) & 1) * STAGE;
           float va[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) va[i] = vs[(i / 4) * VP + 16 * (i % 4)];
@@ -299,8 +301,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
             for (int i = 0; i < 16; ++i) o[i % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[i], s[2 * t][i / 4], o[i % 4], 0, 0, 0);
           }
         }
-        stage ^= 1;
-        if (more) store_tile(stage, !last_v, last_v ? ntwo : two);
+        if (more) store_tile((NS + t + 1) & 1, !last_v, last_v ? ntwo : two);
         __syncthreads();
       }
     }
