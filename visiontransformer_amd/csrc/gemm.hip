@@ -734,6 +734,9 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
     // a small remainder after whole rounds is cut off and run on 64-wide tiles anyway (tail round)
     double e128 = (t128 >= slots && t128 % slots <= 128) ? 0.98 : fill(t128);
     if (t128 < 2 * cus) e128 *= 0.9;  // fewer than two workgroups per CU: latencies show
+    // a short contraction: the 128-wide tile's longer fill and store phases weigh more than its
+    // better operand reuse (M = 50 432, N = 768, K = 192: 103 vs 108 TFLOP/s; no difference from K = 384 on)
+    if (a->K <= 256) e128 *= 0.93;
     const double e64 = fill(t64) * 0.94;
     if (e64 > e128) {
       pl->tile = 64;
