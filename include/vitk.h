@@ -235,7 +235,8 @@ int vitk_sdpa_supported(int32_t N, int32_t dh);
 /* Head dimensions 33..64 with 16-byte-aligned operands run the forward on 16-row tiles with four
  * heads per workgroup (197 tokens = 13 tiles instead of 7 x 32 = 224 rows, every wave busy in
  * every round).  on = 0 keeps them on the 32-row kernel that serves the other head sizes (tests,
- * measurements); the default is on.  Same results to rounding.  Process-wide. */
+ * measurements); the default is on; on >= 2 also fixes the heads per workgroup (otherwise chosen
+ * from the number of heads and the device size).  Same results to rounding.  Process-wide. */
 int vitk_sdpa_tile16_enable(int on);
 /* The same switch for the backward (one launch per call in both forms; the 16-row form deals the
  * key blocks of several heads to the waves of a workgroup: as many heads as it takes for every

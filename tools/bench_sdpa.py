@@ -1,6 +1,6 @@
 """Fused attention forward + backward alone, at a ViT shape (default ViT-B/16, batch 256): a short
 program to put under rocprofv3 (--kernel-trace --stats, or --pmc counters) without the rest of the
-training step.    python tools/bench_sdpa.py [B H N dh [iters]]"""
+training step.    python tools/bench_sdpa.py [B H N dh [iters [heads per workgroup of the backward [of the forward]]]]"""
 import sys
 
 import torch
@@ -11,6 +11,10 @@ vitk.init(0)
 B, H, N, dh = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (256, 12, 197, 64)
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 30
 D, M = H * dh, B * N
+if len(sys.argv) > 6:
+    vitk.check(vitk.dll().vitk_sdpa_bwd_tile16_enable(int(sys.argv[6])))
+if len(sys.argv) > 7:
+    vitk.check(vitk.dll().vitk_sdpa_tile16_enable(int(sys.argv[7])))
 g = torch.Generator(device="cuda").manual_seed(1)
 qkv = torch.randn(M, 3 * D, device="cuda", generator=g)
 do = torch.randn(M, D, device="cuda", generator=g)

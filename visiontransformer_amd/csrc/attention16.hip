@@ -29,8 +29,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HPW = 4;            // heads per workgroup ...
-constexpr int TEAM = 4;           // ... in teams of this many workgroups that share HPW * TEAM heads
+constexpr int TEAM = 4;           // workgroups per team; a team shares TEAM * (heads per workgroup) heads
 constexpr int KP = 65, VP = 68;   // LDS row pitches of a key tile and of a value tile
 constexpr int SLOT = 32 * VP;     // one head's 32-row tile (either kind)
 constexpr int STAGE = 2 * SLOT;   // two heads may be live in one round
@@ -44,6 +43,7 @@ struct Fwd16Params {
   float *stats;            // [B*H][N][2]: row max of the scaled scores, row sum of exp (may be null)
   int B, H, N, dh;
   float scale;
+  int hpw;                 // heads per workgroup (1..4): enough for all workgroups to be resident at once
 };
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -74,14 +74,14 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
   // workgroup on heads of its own, the 96 workgroups resident on an XCD cycle ~10 MB through its
   // 4 MB L2 between two uses and each round's tiles come from memory again (measured: 1.36 GB read
   // per launch for 0.47 GB of operands).  So TEAM workgroups that land on the same XCD (workgroups
-  // go to the 8 XCDs round-robin by index) share TEAM * HPW heads and walk their block list
+  // go to the 8 XCDs round-robin by index) share TEAM * hpw heads and walk their block list
   // together: in round r workgroup j of the team takes blocks 16 r + 4 j .. + 3, so the team is
   // on the same one or two heads at the same time and three of its four tile fetches hit in L2.
   // Placement and pace only matter for speed: results do not depend on either.
   const int xcd = blockIdx.x % 8, slot_in_xcd = blockIdx.x / 8, tj = slot_in_xcd % TEAM;
-  const int head0 = ((slot_in_xcd / TEAM) * 8 + xcd) * (HPW * TEAM);
+  const int head0 = ((slot_in_xcd / TEAM) * 8 + xcd) * (p.hpw * TEAM);
   if (head0 >= BH) return;
-  const int nh = min(HPW * TEAM, BH - head0);
+  const int nh = min(p.hpw * TEAM, BH - head0);
   const int nblk = (p.N + 15) / 16, items = nh * nblk;
   constexpr int RSTEP = 4 * TEAM;  // blocks a team takes per round
   const int first = 4 * tj;        // this workgroup's first block in round 0
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, NS > 7 ? 2 : 3) void sdpa_fwd16_kernel(const F
   }
 }
 
-bool g_tile16_on = true;
+int g_tile16_mode = 1;  // 0 = off, 1 = on, n >= 2 = on with n heads per workgroup (tests, measurements)
 
 }  // namespace
 
@@ -330,7 +330,7 @@ namespace vitk {
 // the softmax takes the maximum of the raw scores, which is the maximum of the scaled ones for a
 // positive scale only; the per-lane offsets into a head are 32-bit)
 bool sdpa_fwd16_applies(int N, int dh, bool vec, float scale, long long ld) {
-  return g_tile16_on && vec && dh > 32 && dh <= DH && N >= 49 && N <= 256 && scale > 0.f && (long long)N * ld * 4 < (1ll << 30);
+  return g_tile16_mode != 0 && vec && dh > 32 && dh <= DH && N >= 49 && N <= 256 && scale > 0.f && (long long)N * ld * 4 < (1ll << 30);
 }
 
 int sdpa_fwd16_launch(const float *q, const float *k, const float *v, long long ld, int B, int H, int N, int dh,
@@ -338,7 +338,14 @@ int sdpa_fwd16_launch(const float *q, const float *k, const float *v, long long 
   Fwd16Params p;
   p.q = q; p.k = k; p.v = v; p.ld = ld; p.out = out; p.ldo = ldo; p.stats = stats;
   p.B = B; p.H = H; p.N = N; p.dh = dh; p.scale = scale;
-  const int teams = (B * H + HPW * TEAM - 1) / (HPW * TEAM);
+  // three workgroups fit a CU: as many heads per workgroup as keep about that many in flight
+  // (ViT-B at batch 256: 3072 heads -> 4; ViT-S: 2; ViT-Ti: 1); more heads per team even out the
+  // last round (13 blocks per head over 16 waves), fewer keep small problems spread over the chip
+  int hpw = B * H / (3 * cu_count());
+  hpw = hpw >= 4 ? 4 : hpw >= 2 ? 2 : 1;
+  if (g_tile16_mode >= 2) hpw = g_tile16_mode;
+  p.hpw = hpw;
+  const int teams = (B * H + hpw * TEAM - 1) / (hpw * TEAM);
   const dim3 grid((unsigned)(8 * TEAM * ((teams + 7) / 8))), blk(256);  // (see Teams in the kernel)
   switch ((N + 31) / 32) {
     case 2: hipLaunchKernelGGL((sdpa_fwd16_kernel<2>), grid, blk, 0, st, p); break;
@@ -355,6 +362,6 @@ int sdpa_fwd16_launch(const float *q, const float *k, const float *v, long long 
 }  // namespace vitk
 
 extern "C" int vitk_sdpa_tile16_enable(int on) {
-  g_tile16_on = on != 0;
+  g_tile16_mode = on < 0 ? 0 : on;
   return 0;
 }
