@@ -7,12 +7,16 @@ namespace {
 
 constexpr int TPB = 256;
 
+// V = 4: four consecutive elements of a patch row per thread (they are consecutive in the image
+// too: P % 4 == 0), 16-byte accesses; V = 1: any shape.
+template <int V>
 __global__ void patch_gather_kernel(const float *__restrict__ img, int B, int C, int HW, int P, int mode,
                                     float *__restrict__ out) {
   const int np = HW / P, pd = P * P * C;
-  const long long total = (long long)B * np * np * pd, img_sz = (long long)C * HW * HW;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
+  const long long total = (long long)B * np * np * pd / V, img_sz = (long long)C * HW * HW;
+  for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const long long i = q * V;
     const int j = (int)(i % pd);
     const long long pidx = i / pd;
     const int pw = (int)(pidx % np), ph = (int)((pidx / np) % np);
@@ -24,7 +28,8 @@ __global__ void patch_gather_kernel(const float *__restrict__ img, int B, int C,
       const int c = j / (P * P), ii = (j / P) % P, jj = j % P;
       src = b * img_sz + ((long long)c * HW + ph * P + ii) * HW + pw * P + jj;
     }
-    out[i] = img[src];
+    if constexpr (V == 4) *reinterpret_cast<float4 *>(out + i) = *reinterpret_cast<const float4 *>(img + src);
+    else out[i] = img[src];
   }
 }
 
@@ -109,29 +114,41 @@ __global__ void augment_kernel(const float *__restrict__ src, const int32_t *__r
   }
 }
 
+template <int V>
 __global__ void embed_assemble_kernel(const float *__restrict__ proj, const float *__restrict__ cls,
                                       const float *__restrict__ pos, int B, int Np, int D, float *__restrict__ out) {
   const int N = Np + 1;
-  const long long total = (long long)B * N * D;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
+  const long long total = (long long)B * N * D / V;
+  for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const long long i = q * V;
     const int d = (int)(i % D);
     const int n = (int)((i / D) % N);
     const long long b = i / ((long long)D * N);
-    const float base = n == 0 ? cls[d] : proj[(b * Np + (n - 1)) * D + d];
-    out[i] = base + pos[(long long)n * D + d];
+    const float *base = n == 0 ? cls + d : proj + (b * Np + (n - 1)) * D + d;
+    const float *pp = pos + (long long)n * D + d;
+    if constexpr (V == 4) {
+      const float4 a = *reinterpret_cast<const float4 *>(base), c = *reinterpret_cast<const float4 *>(pp);
+      *reinterpret_cast<float4 *>(out + i) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    } else {
+      out[i] = *base + *pp;
+    }
   }
 }
 
+template <int V>
 __global__ void embed_split_kernel(const float *__restrict__ dy, int B, int Np, int D, float *__restrict__ dproj) {
   const int N = Np + 1;
-  const long long total = (long long)B * Np * D;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
+  const long long total = (long long)B * Np * D / V;
+  for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const long long i = q * V;
     const int d = (int)(i % D);
     const int p = (int)((i / D) % Np);
     const long long b = i / ((long long)D * Np);
-    dproj[i] = dy[(b * N + 1 + p) * D + d];
+    const float *src = dy + (b * N + 1 + p) * D + d;
+    if constexpr (V == 4) *reinterpret_cast<float4 *>(dproj + i) = *reinterpret_cast<const float4 *>(src);
+    else dproj[i] = *src;
   }
 }
 
@@ -182,8 +199,12 @@ int vitk_patch_gather(const float *img, int32_t B, int32_t C, int32_t HW, int32_
                        (long long)C * HW * HW,
                "vitk_patch_gather: reference-mode run of the last patch leaves the image");
   const long long total = (long long)B * np * np * P * P * C;
-  hipLaunchKernelGGL(patch_gather_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream), img,
-                     B, C, HW, P, mode, patches);
+  if (P % 4 == 0 && vitk::aligned16(img) && vitk::aligned16(patches))
+    hipLaunchKernelGGL(patch_gather_kernel<4>, dim3(vitk::grid_for(total / 4, TPB)), dim3(TPB), 0,
+                       vitk::as_stream(stream), img, B, C, HW, P, mode, patches);
+  else
+    hipLaunchKernelGGL(patch_gather_kernel<1>, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                       img, B, C, HW, P, mode, patches);
   return vitk::check_launch("vitk_patch_gather");
 }
 
@@ -205,8 +226,12 @@ int vitk_embed_assemble(const float *proj, const float *cls, const float *pos, i
   if (B == 0) return 0;
   VITK_REQUIRE((proj || Np == 0) && cls && pos && out, "vitk_embed_assemble: null pointer");
   const long long total = (long long)B * (Np + 1) * D;
-  hipLaunchKernelGGL(embed_assemble_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
-                     proj, cls, pos, B, Np, D, out);
+  if (D % 4 == 0 && vitk::aligned16(proj) && vitk::aligned16(cls) && vitk::aligned16(pos) && vitk::aligned16(out))
+    hipLaunchKernelGGL(embed_assemble_kernel<4>, dim3(vitk::grid_for(total / 4, TPB)), dim3(TPB), 0,
+                       vitk::as_stream(stream), proj, cls, pos, B, Np, D, out);
+  else
+    hipLaunchKernelGGL(embed_assemble_kernel<1>, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0,
+                       vitk::as_stream(stream), proj, cls, pos, B, Np, D, out);
   return vitk::check_launch("vitk_embed_assemble");
 }
 
@@ -215,8 +240,12 @@ int vitk_embed_split_bwd(const float *dy, int32_t B, int32_t Np, int32_t D, floa
   if (B == 0 || Np == 0) return 0;
   VITK_REQUIRE(dy && dproj, "vitk_embed_split_bwd: null pointer");
   const long long total = (long long)B * Np * D;
-  hipLaunchKernelGGL(embed_split_kernel, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream), dy, B,
-                     Np, D, dproj);
+  if (D % 4 == 0 && vitk::aligned16(dy) && vitk::aligned16(dproj))
+    hipLaunchKernelGGL(embed_split_kernel<4>, dim3(vitk::grid_for(total / 4, TPB)), dim3(TPB), 0,
+                       vitk::as_stream(stream), dy, B, Np, D, dproj);
+  else
+    hipLaunchKernelGGL(embed_split_kernel<1>, dim3(vitk::grid_for(total, TPB)), dim3(TPB), 0, vitk::as_stream(stream),
+                       dy, B, Np, D, dproj);
   return vitk::check_launch("vitk_embed_split_bwd");
 }
 
