@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--dense-tail", action="store_true",
                     help="compute every token of the last encoder block as the reference does, instead of only the "
                          "CLS token that the classification head reads (same results; see include/vit_host.h)")
+    ap.add_argument("--eval", action="store_true",
+                    help="time the evaluation path instead (Trainer::evaluate's per-batch body: forward with dropout "
+                         "off + arg-max on the device; its own metric name, no roofline object)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="dropout rate (0 = the headline/parity configuration; 0.1 adds the device RNG cost)")
     args = ap.parse_args()
@@ -178,6 +181,39 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.eval:
+        # forward only, one rank's batch per step, nothing exchanged between ranks
+        for s in range(args.warmup):
+            pred = model.predict(x)
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            pred = model.predict(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if rank == 0:
+            f_fwd = train_flops_per_image(cfgd) / 3
+            value = batch * world * args.steps / elapsed
+            out = {"metric": "eval images/sec (forward + arg-max, dropout off)", "value": round(value, 2),
+                   "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": args.workload, "batch_per_gpu": batch, "global_batch": batch * world,
+                              "last_block": "all tokens" if args.dense_tail else "CLS token only after its keys/values",
+                              "forward_gflop_per_image": round(f_fwd / 1e9, 2),
+                              "frac_of_fp32_mfma_peak": round(value / world * f_fwd / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              "classes_predicted": int(pred.unique().numel())}}
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if dist.is_initialized():
+            dist.barrier()
+            host.comm_destroy()
+            dist.destroy_process_group()
+        return
 
     for s in range(args.warmup):
         ddp.step(x, y, lr(s))
