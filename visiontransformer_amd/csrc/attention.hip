@@ -693,12 +693,11 @@ int launch_fwd(const SdpaParams &p, int grid, hipStream_t st) {
 template <int DHP, bool VEC>
 int launch_bwd(const SdpaParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = 2 * DkvStage<DHP>::value * sizeof(float);
-  static bool configured = false;  // raise the dynamic LDS limit once per instantiation
-  if (!configured) {
+  static std::atomic<unsigned long long> configured{0};  // raise the dynamic LDS limit once per instantiation and device
+  if (vitk::first_use_on_device(&configured)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd_dkv_kernel<DHP, VEC>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     VITK_REQUIRE(e == hipSuccess, "vitk_sdpa_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    configured = true;
   }
   hipLaunchKernelGGL((sdpa_bwd_dq_kernel<DHP, VEC>), grid, dim3(THREADS), 0, st, p);
   hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<DHP, VEC>), grid, dim3(THREADS), lds, st, p);
@@ -707,12 +706,11 @@ int launch_bwd(const SdpaParams &p, dim3 grid, hipStream_t st) {
 
 int launch_bwd_fused(const SdpaParams &p, hipStream_t st) {
   const size_t lds = F_LDS_FLOATS * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
+  static std::atomic<unsigned long long> configured{0};
+  if (vitk::first_use_on_device(&configured)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd_fused_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     VITK_REQUIRE(e == hipSuccess, "vitk_sdpa_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    configured = true;
   }
   hipLaunchKernelGGL(sdpa_bwd_fused_kernel, dim3((unsigned)(p.B * p.H)), dim3(FT), lds, st, p);
   return vitk::check_launch("vitk_sdpa_bwd");

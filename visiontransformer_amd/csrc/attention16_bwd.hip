@@ -408,12 +408,11 @@ int sdpa_bwd16_launch(const float *q, const float *k, const float *v, long long 
                       long long ldo, const float *stats, int B, int H, int N, int dh, float scale, int dk_mode,
                       float *dq, float *dk, float *dv, long long ldg, hipStream_t st) {
   const size_t lds = F_TOTAL * sizeof(float);
-  static bool configured = false;  // raise the dynamic LDS limit once (idempotent; set per process)
-  if (!configured) {
+  static std::atomic<unsigned long long> configured{0};  // raise the dynamic LDS limit once per device
+  if (vitk::first_use_on_device(&configured)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sdpa_bwd16_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     VITK_REQUIRE(e == hipSuccess, "vitk_sdpa_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    configured = true;
   }
   Bwd16Params p;
   p.q = q; p.k = k; p.v = v; p.ld = (int)ld; p.o = o; p.dout = dout; p.ldo = (int)ldo; p.stats = stats;

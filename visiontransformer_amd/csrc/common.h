@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 
 #include "vitk.h"
 
@@ -39,6 +40,8 @@ int sdpa_bwd16_launch(const float *q, const float *k, const float *v, long long 
 // Compute units of the current device (hipDeviceProp_t::multiProcessorCount), cached per device;
 // 256 if the query fails.
 int cu_count();
+// first call with this flag word on the current device?
+bool first_use_on_device(std::atomic<unsigned long long> *done);
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -35,6 +35,15 @@ int cu_count() {
   return cached[dev];
 }
 
+// True the first time it is called with `done` on the current device (one bit per device), so that
+// per-function attributes are set on every device a process uses, not just the first.
+bool first_use_on_device(std::atomic<unsigned long long> *done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown device: set again (idempotent)
+  const unsigned long long bit = 1ull << dev;
+  return (done->fetch_or(bit) & bit) == 0;
+}
+
 }  // namespace vitk
 
 extern "C" {
