@@ -683,18 +683,28 @@ struct Plan {
 
 int choose_split(long long tiles, int K) {
   // Weight-gradient GEMMs contract over all B*N token rows into a small [in][out] matrix: too few
-  // output tiles to occupy the chip's CUs (256 on MI355X).  Split the contraction so that tiles*splits comes just under
-  // one full round of resident workgroups (CUs x kBlocksPerCU): every workgroup then runs
-  // concurrently and they all finish together -- a second, mostly empty round would cost as much
-  // as the first.
+  // output tiles to occupy the chip's CUs (256 on MI355X).  Split the contraction so that
+  // tiles*splits fills whole rounds of resident workgroups (CUs x kBlocksPerCU): the workgroups of
+  // a round run concurrently and finish together, and a partly empty round costs as much as a
+  // full one.  Which number of rounds: the fill of the last round against the reduction launch's
+  // reading of one more partial result per split -- relative to the contraction, 2 S F / (K BW)
+  // with F / BW ~ 135 TFLOP/s / 5 TB/s, i.e. 54 S / K.  (ViT-B's 768 x 3072 gradients: 144 tiles;
+  // 5 splits fill 94 % of one round, 16 splits fill three rounds exactly and run 5.5 % faster;
+  // 108- and 36-tile outputs stay at one round of 7 and 21 splits -- measured, tools/bench_gemm_split.py.)
   const long long slots = (long long)vitk::cu_count() * kBlocksPerCU;
   if (tiles >= slots / 2) return 1;
-  long long want = slots / tiles;
-  long long max_by_k = K / (8 * BK);
-  if (max_by_k < 1) max_by_k = 1;
-  if (want > max_by_k) want = max_by_k;
-  if (want > 64) want = 64;
-  return (int)(want < 1 ? 1 : want);
+  long long max_s = K / (8 * BK);
+  if (max_s > 64) max_s = 64;
+  if (max_s < 1) max_s = 1;
+  int best_s = 1;
+  double best = -1.0;
+  for (long long s = 1; s <= max_s; ++s) {
+    const long long wgs = tiles * s, rounds = (wgs + slots - 1) / slots;
+    const double fill = (double)wgs / (double)(rounds * slots);
+    const double score = fill / (1.0 + 54.0 * (double)s / (double)K);
+    if (score > best) best = score, best_s = (int)s;
+  }
+  return best_s;
 }
 
 int make_plan(const vitk_gemm_args *a, Plan *pl) {
