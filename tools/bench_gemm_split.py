@@ -26,7 +26,7 @@ for name, rows, m, n in cases:
     line = f"{name:11s} K={rows:6d} {m:4d}x{n:4d}:"
     tile = 128 if (m >= 128 and n >= 128 and m % 128 == 0 and n % 128 == 0) else 64
     tiles = ((m + tile - 1) // tile) * ((n + tile - 1) // tile)
-    gens = sorted({max(1, min(64, (g * 768) // tiles)) for g in (1, 2, 3, 4, 5, 6)})
+    gens = sorted({max(1, min(128, (g * 768) // tiles)) for g in (1, 2, 3, 4, 5, 6)} | {64})
     line += f" ({tiles} tiles of {tile})"
     for split in [0] + gens:
         ts = []
