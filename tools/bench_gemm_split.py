@@ -28,7 +28,8 @@ for name, rows, m, n in cases:
     tiles = ((m + tile - 1) // tile) * ((n + tile - 1) // tile)
     gens = sorted({max(1, min(128, (g * 768) // tiles)) for g in (1, 2, 3, 4, 5, 6)} | {64})
     line += f" ({tiles} tiles of {tile})"
-    for split in [0] + gens:
+    import sys
+    for split in ([0] if len(sys.argv) > 1 and sys.argv[1] == "--auto" else [0] + gens):
         ts = []
         try:
             for it in range(6):
