@@ -704,6 +704,12 @@ int choose_split(long long tiles, int K) {
     const double score = fill / (1.0 + 54.0 * (double)s / (double)K);
     if (score > best) best = score, best_s = (int)s;
   }
+  // A contraction too short for that (fewer than 32 slabs per workgroup at the chosen split: the
+  // 8704-row gradients of the 17-token model) is all fill, drain and reduction; one workgroup per
+  // CU then beats three, with a third of the partial results to write and re-read (192 x 192:
+  // 28 vs 19 us at 68 / 28 splits; 192 x 768: 53 vs 41 us at 64 / 21).
+  const long long per_cu = vitk::cu_count() / tiles;
+  if (K / (best_s * BK) < 32 && per_cu >= 1 && per_cu < best_s) best_s = (int)per_cu;
   return best_s;
 }
 
