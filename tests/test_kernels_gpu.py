@@ -493,7 +493,11 @@ def test_dk_reference_scatter(K):
 
 
 @pytest.mark.parametrize("M,N,Kd,split", [(96, 384, 640, 1), (96, 384, 640, 0), (768, 768, 6400, 0), (75, 130, 257, 1),
-                                          (192, 64, 8704, 0), (128, 128, 16, 1), (40, 10, 33, 4)])
+                                          (192, 64, 8704, 0), (128, 128, 16, 1), (40, 10, 33, 4),
+                                          # the library's own split count in its three regimes: three whole rounds of
+                                          # workgroups (144 tiles x 16 splits), more splits than tiles x 64 (9 tiles),
+                                          # one workgroup per CU on a short contraction
+                                          (768, 3072, 12800, 0), (384, 384, 12800, 0), (192, 192, 8704, 0)])
 def test_gemm_fused_column_sums_of_b(K, M, N, Kd, split):
     """dW = X^T dY with db = dY.sum(0) from the same launch (Dense::backward, src/layers/Dense.cpp:90-95)."""
     x, dy = V.rng_normal(5, Kd, M), V.rng_normal(6, Kd, N)
