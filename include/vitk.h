@@ -127,8 +127,12 @@ int vitk_colsum_f32(const float *x, int64_t rows, int64_t cols, int64_t ldx, flo
  * backward: dx = (1/D)*inv_std*(D*dxhat - sum(dxhat) - xhat*sum(dxhat*xhat)), dxhat = dy*gamma;
  * if `residual` is non-NULL it is added to dx (the skip branch of the block's backward,
  * src/model/TransformerEncoderBlock.cpp:52,63).  dgamma/dbeta are reduced over rows in two
- * fixed-order stages.  Rows are `row_stride` elements apart (row_stride >= D). */
+ * fixed-order stages (per-workgroup partials in the workspace, then a reduction launch); with at
+ * most 1024 rows and aligned operands everything happens in one launch (a fixed-order sum per
+ * column, the workspace is not touched) unless vitk_layernorm_small_enable(0) turned that off
+ * (tests, measurements; process-wide).  Rows are `row_stride` elements apart (row_stride >= D). */
 size_t vitk_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D);
+int vitk_layernorm_small_enable(int on);
 int vitk_layernorm_fwd(const float *x, int64_t rows, int64_t D, int64_t row_stride, const float *gamma,
                        const float *beta, float eps, float *y, float *mean, float *inv_std, vitk_stream_t stream);
 int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *inv_std, const float *gamma,

@@ -46,8 +46,21 @@ def sdpa_path(request, K):
     K.sdpa_tile16(True)
 
 
+@pytest.fixture
+def ln_path(request, K):
+    """Every test_layernorm_* runs twice: few rows in one launch (the default) and on the two-stage
+    kernels that serve larger inputs."""
+    K.check(K.dll().vitk_layernorm_small_enable(int(request.param == "one_launch")))
+    yield request.param
+    K.check(K.dll().vitk_layernorm_small_enable(1))
+
+
 def pytest_generate_tests(metafunc):
     name = metafunc.function.__name__
+    if name.startswith("test_layernorm_"):
+        if "ln_path" not in metafunc.fixturenames:
+            metafunc.fixturenames.append("ln_path")
+        metafunc.parametrize("ln_path", ["one_launch", "two_stage"], indirect=True)
     if name.startswith("test_gemm_"):
         if "gemm_path" not in metafunc.fixturenames:
             metafunc.fixturenames.append("gemm_path")
@@ -182,7 +195,8 @@ def test_gemm_batched_strided_heads(K):
 
 
 # ----------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize("rows,D", [(50, 96), (640, 64), (333, 768), (77, 192), (19, 1000), (9, 100), (6, 1030)])
+@pytest.mark.parametrize("rows,D", [(50, 96), (640, 64), (333, 768), (77, 192), (19, 1000), (9, 100), (6, 1030), (1024, 96),
+                                    (1500, 384)])
 def test_layernorm_fwd_bwd_vs_oracle(K, rows, D):
     O = V.oracle()
     g, b = 1 + V.rng_normal(1, D) * 0.1, V.rng_normal(2, D) * 0.1

@@ -42,8 +42,10 @@ def test_static_scratch_layernorm_backward_matches_the_workspace_entry_point():
     K.init(0)
     assert K.dll().vitk_layernorm_bwd_static_max_d() == 1024
     # a large call first (1024 workgroups of partials, D = 768), then smaller ones that leave most
-    # of the array holding stale partials, then the generic (unaligned D) path
-    for rows, D, stride, res in ((50432, 768, 768, True), (640, 96, 96, False), (37, 100, 104, True), (5, 30, 30, False),
+    # of the array holding stale partials (2000 and 1100 rows; the calls of at most 1024 rows take
+    # the one-launch path that needs no partials at all), then the generic (unaligned D) path
+    for rows, D, stride, res in ((50432, 768, 768, True), (2000, 192, 192, True), (640, 96, 96, False),
+                                 (1100, 96, 100, False), (37, 100, 104, True), (5, 30, 30, False),
                                  (4100, 1024, 1024, True)):
         (dx0, dg0, db0), (dx1, dg1, db1) = _run_both(K, torch, rows, D, stride, 11 + rows, res)
         assert np.array_equal(dx0, dx1), (rows, D)

@@ -189,6 +189,99 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const float *__restrict__ d
   }
 }
 
+// Few rows (at most kSmallRows: the 17- and 5-token models, the CLS rows of the final norm): dx and
+// both parameter gradients in ONE launch, no partials.  Sixteen-wave workgroups; the first
+// `row_blocks` of them give every wave one row of dx, the others own 64 columns each and sum
+// them over all rows (wave w takes rows w, w + 16, ...; the sixteen sums are combined in wave
+// order through LDS).  The column workgroups read dy and x a second time -- from L2 at these
+// sizes -- which costs less than a second launch.
+constexpr int SM_WAVES = 16;
+constexpr long long kSmallRows = 1024;
+template <int NV>
+__global__ __launch_bounds__(64 * SM_WAVES) void ln_bwd_small_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
+    const float *__restrict__ inv_std, const float *__restrict__ gamma, long long rows, int D, long long stride,
+    const float *__restrict__ residual, float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    int row_blocks) {
+  __shared__ float sm[2][SM_WAVES][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if ((int)blockIdx.x < row_blocks) {
+    const long long row = blockIdx.x * (long long)SM_WAVES + wv;
+    if (row >= rows) return;
+    const float fD = (float)D, invD = 1.0f / (float)D;
+    const float mu = mean[row], inv = inv_std[row];
+    float4 g[NV], xh[NV], gm[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < D) {
+        gm[j] = *reinterpret_cast<const float4 *>(gamma + c);
+        g[j] = *reinterpret_cast<const float4 *>(dy + row * stride + c);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + row * stride + c);
+        xh[j] = make_float4((xv.x - mu) * inv, (xv.y - mu) * inv, (xv.z - mu) * inv, (xv.w - mu) * inv);
+      } else {
+        gm[j] = g[j] = xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const float a = g[j].x * gm[j].x, b = g[j].y * gm[j].y, c2 = g[j].z * gm[j].z, d = g[j].w * gm[j].w;
+      s1 += (a + b) + (c2 + d);
+      s2 += (a * xh[j].x + b * xh[j].y) + (c2 * xh[j].z + d * xh[j].w);
+    }
+    s1 = vitk::wave_sum(s1);
+    s2 = vitk::wave_sum(s2);
+    const float f = invD * inv;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < D) {
+        float4 o;
+        o.x = f * (fD * (g[j].x * gm[j].x) - s1 - xh[j].x * s2);
+        o.y = f * (fD * (g[j].y * gm[j].y) - s1 - xh[j].y * s2);
+        o.z = f * (fD * (g[j].z * gm[j].z) - s1 - xh[j].z * s2);
+        o.w = f * (fD * (g[j].w * gm[j].w) - s1 - xh[j].w * s2);
+        if (residual) {
+          const float4 r = *reinterpret_cast<const float4 *>(residual + row * stride + c);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        *reinterpret_cast<float4 *>(dx + row * stride + c) = o;
+      }
+    }
+    return;
+  }
+  const int c = ((int)blockIdx.x - row_blocks) * 64 + lane;
+  constexpr int U = 8;  // rows in flight per thread: the sum is a handful of memory round trips
+  float a[U], b[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = 0.f, b[u] = 0.f;
+  if (c < D) {
+    long long row = wv;
+    for (; row + (U - 1) * SM_WAVES < rows; row += U * SM_WAVES) {
+      float gv[U], xv[U], mu[U], iv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long r = row + u * SM_WAVES;
+        gv[u] = dy[r * stride + c], xv[u] = x[r * stride + c], mu[u] = mean[r], iv[u] = inv_std[r];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] += gv[u] * ((xv[u] - mu[u]) * iv[u]), b[u] += gv[u];
+    }
+    for (; row < rows; row += SM_WAVES) {
+      const float gv = dy[row * stride + c];
+      a[0] += gv * ((x[row * stride + c] - mean[row]) * inv_std[row]);
+      b[0] += gv;
+    }
+  }
+  sm[0][wv][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  sm[1][wv][lane] = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
+  __syncthreads();
+  if (wv < 2 && c < D) {  // wave 0: dgamma, wave 1: dbeta
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SM_WAVES; ++w) t += sm[wv][w][lane];
+    (wv == 0 ? dgamma : dbeta)[c] = t;
+  }
+}
+
 // generic dgamma/dbeta partials: workgroup b handles rows b, b+grid, ...; thread per column.
 __global__ void ln_param_grad_generic(const float *__restrict__ dy, const float *__restrict__ x,
                                       const float *__restrict__ mean, const float *__restrict__ inv_std,
@@ -258,6 +351,8 @@ __global__ void colsum_stage1(const float *__restrict__ x, long long rows, long 
   for (; r < r1; ++r) s0 += x[r * ldx + c];
   partial[blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
 }
+
+bool g_ln_small_on = true;
 
 int ln_blocks(long long rows) {
   long long b = (rows + WPB - 1) / WPB;
@@ -411,6 +506,20 @@ int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const
   const dim3 grid(nblk), blk(TPB);
   const bool vec = ln_vec_ok(dy, x, gamma, dx, D, row_stride) && (residual == nullptr || vitk::aligned16(residual));
   const int nv = vec ? (int)((D + 255) / 256) : 0;
+  if (g_ln_small_on && nv >= 1 && nv <= 4 && rows <= kSmallRows) {
+    const int row_blocks = (int)((rows + SM_WAVES - 1) / SM_WAVES), col_blocks = (int)((D + 63) / 64);
+    const dim3 sgrid((unsigned)(row_blocks + col_blocks)), sblk(64 * SM_WAVES);
+#define LNS(NV) hipLaunchKernelGGL((ln_bwd_small_kernel<NV>), sgrid, sblk, 0, st, dy, x, mean, inv_std, gamma, \
+                                   (long long)rows, (int)D, (long long)row_stride, residual, dx, dgamma, dbeta, row_blocks)
+    switch (nv) {
+      case 1: LNS(1); break;
+      case 2: LNS(2); break;
+      case 3: LNS(3); break;
+      default: LNS(4); break;
+    }
+#undef LNS
+    return vitk::check_launch("vitk_layernorm_bwd");
+  }
 #define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, blk, 0, st, dy, x, mean, inv_std, gamma, \
                                    (long long)rows, (int)D, (long long)row_stride, residual, dx, workspace)
   switch (nv) {
@@ -432,6 +541,11 @@ int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const
   hipLaunchKernelGGL(reduce_partials_kernel, rg, dim3(RED_COLS * RED_WAVES), 0, st, workspace, nblk,
                      (long long)(2 * D), (long long)(2 * D), (long long)D, dgamma, dbeta);
   return vitk::check_launch("vitk_layernorm_bwd/final");
+}
+
+int vitk_layernorm_small_enable(int on) {
+  g_ln_small_on = on != 0;
+  return 0;
 }
 
 size_t vitk_layernorm_bwd_static_max_d(void) { return (size_t)kStaticMaxD; }

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vitk_layernorm_fwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _f, _p, _p, _p, _p]),
     "vitk_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "vitk_layernorm_bwd_static_max_d": (_sz, []),
+    "vitk_layernorm_small_enable": (C.c_int, [C.c_int]),
     "vitk_layernorm_bwd_static": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
     "vitk_gelu_fwd": (C.c_int, [_p, _i64, _p, _p]),
     "vitk_gelu_bwd": (C.c_int, [_p, _p, _i64, _p, _p]),
