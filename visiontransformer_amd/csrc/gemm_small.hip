@@ -7,7 +7,7 @@
 // reference (vit_mnist_4_8: 5 tokens, 96 features) consist of nothing but such contractions.
 // Here nothing is staged or shared: each wave reads its 16 rows of A and 16 columns of B straight
 // from global memory (they come from L2 after the first touch) in the operand layout of
-// v_mfma_f32_16x16x4_f32, four k-chunks of loads in flight ahead of the multiplies, and the whole
+// v_mfma_f32_16x16x4_f32, eight k-chunks of loads in flight ahead of the multiplies, and the whole
 // problem is spread over as many SIMDs as it has 16 x 16 tiles.  Same epilogue and the same
 // column-sum side output as vitk_gemm_f32.
 #include "common.h"
@@ -35,7 +35,7 @@ struct SmallParams {
   int tiles_n;
 };
 
-constexpr int U = 4;  // k-chunks (of 16) per batch of loads
+constexpr int U = 8;  // k-chunks (of 16) per batch of loads (4: +5 % step time on the 5-token model; 16 spills)
 
 // Four consecutive k (k0 .. k0+3) of one row of A or one column of B; `base` points at k = 0 of it.
 // VEC: k is contiguous in memory and the 16 bytes are aligned.  TAIL: k may run past K -- the
