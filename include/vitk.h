@@ -108,8 +108,10 @@ const char *vitk_gemm_variant_name(int variant);
  * forced split run on a kernel of their own (one wave per tile, operands straight from global
  * memory: on a nearly idle chip the tiled kernel's slab pipeline is pure latency).  Same
  * arguments, epilogue and colsum_b; the summation order over k differs, so results agree with the
- * tiled kernel to rounding, not bitwise.  on = 0 keeps everything on the tiled kernel (tests,
- * measurements); the default is on.  Process-wide. */
+ * tiled kernel to rounding, not bitwise.  In the weight-gradient form (trans_a, not trans_b) with K > 128 and SIMDs
+ * to spare, up to eight waves share a tile, 128 k each (one round trip to memory per wave), and add their
+ * results in wave order.  on = 0 keeps everything on the tiled kernel, on = 2 keeps the small kernel at one wave
+ * per tile (tests, measurements); the default is 1.  Process-wide. */
 int vitk_gemm_small_enable(int on);
 
 /* ---- column sum: out[j] = sum_i x[i][j]  (Tensor::sum(0), src/core/Tensor.cpp:385-430; the

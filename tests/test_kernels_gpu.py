@@ -27,11 +27,12 @@ def K():
 
 @pytest.fixture
 def gemm_path(request, K):
-    """Every test_gemm_* runs twice: with small problems routed to the one-wave-per-tile kernel (the
-    default) and with everything kept on the tiled kernel."""
-    K.gemm_small(request.param == "small_kernel_on")
+    """Every test_gemm_* runs three times: with small problems routed to the one-wave-per-tile kernel
+    (the default: four waves per tile where the contraction is long), with that kernel kept to one
+    wave per tile, and with everything on the tiled kernel."""
+    K.gemm_small({"small_kernel_on": 1, "small_kernel_one_wave": 2, "tiled_only": 0}[request.param])
     yield request.param
-    K.gemm_small(True)
+    K.gemm_small(1)
 
 
 @pytest.fixture
@@ -64,7 +65,7 @@ def pytest_generate_tests(metafunc):
     if name.startswith("test_gemm_"):
         if "gemm_path" not in metafunc.fixturenames:
             metafunc.fixturenames.append("gemm_path")
-        metafunc.parametrize("gemm_path", ["small_kernel_on", "tiled_only"], indirect=True)
+        metafunc.parametrize("gemm_path", ["small_kernel_on", "small_kernel_one_wave", "tiled_only"], indirect=True)
     if name.startswith("test_sdpa_") and "row" not in name:
         if "sdpa_path" not in metafunc.fixturenames:
             metafunc.fixturenames.append("sdpa_path")

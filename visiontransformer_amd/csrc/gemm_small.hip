@@ -8,8 +8,12 @@
 // Here nothing is staged or shared: each wave reads its 16 rows of A and 16 columns of B straight
 // from global memory (they come from L2 after the first touch) in the operand layout of
 // v_mfma_f32_16x16x4_f32, eight k-chunks of loads in flight ahead of the multiplies, and the whole
-// problem is spread over as many SIMDs as it has 16 x 16 tiles.  Same epilogue and the same
-// column-sum side output as vitk_gemm_f32.
+// problem is spread over as many SIMDs as it has 16 x 16 tiles -- times up to eight where the
+// contraction is longer than one batch of loads and the tiles are few (the weight gradients of
+// the 5-token model: 36 .. 144 tiles, K = 640): every wave of a workgroup then takes one batch
+// (128 k, a single round trip to memory) and the accumulators are added in wave order through
+// LDS (7.5 -> 5.2 us for those gradients; a four-way split with 1.25 batches per wave ran 10 us).  Same epilogue and the same column-sum side output as
+// vitk_gemm_f32.
 #include "common.h"
 
 namespace {
@@ -33,6 +37,7 @@ struct SmallParams {
   long long ldaux;
   float *colsum;
   int tiles_n;
+  int k_per_wave;  // SPLIT > 1: the share of k of each wave (one batch of loads)
 };
 
 constexpr int U = 8;  // k-chunks (of 16) per batch of loads (4: +5 % step time on the 5-token model; 16 spills)
@@ -63,9 +68,12 @@ __device__ __forceinline__ f32x4 load4(const float *__restrict__ base, long long
   return v;
 }
 
-template <bool AV, bool BV>
-__global__ __launch_bounds__(64) void gemm_small_kernel(const SmallParams p) {
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+template <bool AV, bool BV, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void gemm_small_kernel(const SmallParams p) {
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = SPLIT > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const int kb = SPLIT > 1 ? min(wave * p.k_per_wave, p.K) : 0;            // this wave's k: [kb, ke)
+  const int ke = SPLIT > 1 ? min(kb + p.k_per_wave, p.K) : p.K;
   const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
   // lane (c, g) feeds row m of A and column n of B at k = 16*chunk + 4*g + e into step e of the
   // chunk: v_mfma_f32_16x16x4_f32 takes A[i = lane % 16][k = lane / 16] and B[k = lane / 16][j = lane % 16].
@@ -79,21 +87,21 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const SmallParams p) {
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, csum = acc0;
   f32x4 a0[U], b0[U], a1[U], b1[U];
-  const int nfull = p.K / (16 * U);                     // batches with every k inside the contraction
-  const int nbatch = (p.K + 16 * U - 1) / (16 * U);     // nfull, or one more (ragged)
+  const int nfull = (ke - kb) / (16 * U);                   // batches with every k inside the contraction
+  const int nbatch = (ke - kb + 16 * U - 1) / (16 * U);     // nfull, or one more (ragged)
 
 #define VITK_LOAD(BATCH, RA, RB)                                              \
   if ((BATCH) < nfull) {                                                      \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                           \
-      const int k0 = ((BATCH)*U + u) * 16 + 4 * g;                            \
-      RA[u] = load4<AV, false>(ap, p.sak, k0, p.K);                           \
-      RB[u] = load4<BV, false>(bp, p.sbk, k0, p.K);                           \
+      const int k0 = kb + ((BATCH)*U + u) * 16 + 4 * g;                       \
+      RA[u] = load4<AV, false>(ap, p.sak, k0, ke);                            \
+      RB[u] = load4<BV, false>(bp, p.sbk, k0, ke);                            \
     }                                                                         \
   } else {                                                                    \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                           \
-      const int k0 = ((BATCH)*U + u) * 16 + 4 * g;                            \
-      RA[u] = load4<AV, true>(ap, p.sak, k0, p.K);                            \
-      RB[u] = load4<BV, true>(bp, p.sbk, k0, p.K);                            \
+      const int k0 = kb + ((BATCH)*U + u) * 16 + 4 * g;                       \
+      RA[u] = load4<AV, true>(ap, p.sak, k0, ke);                             \
+      RB[u] = load4<BV, true>(bp, p.sbk, k0, ke);                             \
     }                                                                         \
   }
   // two accumulators (even / odd chunks): a chain of dependent 16x16x4 MFMAs issues every 40
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const SmallParams p) {
     csum += RB[u];                                                                          \
   }
 
-  VITK_LOAD(0, a0, b0)
+  if (nbatch > 0) { VITK_LOAD(0, a0, b0) }
   for (int bt = 0; bt < nbatch; bt += 2) {
     if (bt + 1 < nbatch) { VITK_LOAD(bt + 1, a1, b1) }
     VITK_MULTIPLY(a0, b0)
@@ -117,6 +125,16 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const SmallParams p) {
 #undef VITK_LOAD
 #undef VITK_MULTIPLY
 
+  f32x4 acc = acc0 + acc1;
+  if constexpr (SPLIT > 1) {  // add the waves' shares in wave order; wave 0 carries on alone
+    __shared__ f32x4 part[2][SPLIT][64];
+    part[0][wave][lane] = acc;
+    part[1][wave][lane] = csum;
+    __syncthreads();
+    if (wave != 0) return;
+    const int nw = (int)(blockDim.x >> 6);
+    for (int w = 1; w < nw; ++w) acc += part[0][w][lane], csum += part[1][w][lane];
+  }
   if (do_colsum) {  // wave-uniform
     // this lane added B[k][n] over its k (4g + e of every chunk); the other three k-groups of the
     // column sit 16, 32 and 48 lanes away.  Fixed order.
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const SmallParams p) {
   for (int r = 0; r < 4; ++r) {
     const int row = tm * 16 + 4 * g + r;
     if (row >= p.M) continue;
-    float v = p.alpha * (acc0[r] + acc1[r]);
+    float v = p.alpha * acc[r];
     if (p.act == VITK_ACT_GELU_BWD) v *= vitk::gelu_grad(p.aux[(long long)row * p.ldaux + n]);
     v += bv;
     if (p.act == VITK_ACT_GELU_FWD) {
@@ -146,6 +164,7 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(const SmallParams p) {
 }
 
 bool g_small_on = true;
+bool g_small_split_on = true;
 
 }  // namespace
 
@@ -173,17 +192,34 @@ int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st) {
   p.tiles_n = (a->N + 15) / 16;
   const bool av = !a->trans_a && a->lda % 4 == 0 && a->K % 4 == 0 && aligned16(a->A);
   const bool bv = a->trans_b && a->ldb % 4 == 0 && a->K % 4 == 0 && aligned16(a->B);
-  const dim3 grid((unsigned)(((a->M + 15) / 16) * p.tiles_n)), blk(64);
-  if (av && bv) hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, blk, 0, st, p);
-  else if (av) hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, blk, 0, st, p);
-  else if (bv) hipLaunchKernelGGL((gemm_small_kernel<false, true>), grid, blk, 0, st, p);
-  else hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, blk, 0, st, p);
+  const long long tiles = (long long)((a->M + 15) / 16) * p.tiles_n;
+  const dim3 grid((unsigned)tiles);
+  // a long contraction over few tiles: four waves per tile, a quarter of k each, while that still
+  // leaves (nearly) every wave a SIMD of its own
+  // (one batch of loads = 16 * U k per wave: every wave makes a single round trip to memory)
+  const int nw = (a->K + 16 * U - 1) / (16 * U);
+  // Only for the weight-gradient form (A^T B: k runs over the token rows, up to 1024 of them
+  // here).  Those results go straight into the optimizer; activations and activation gradients
+  // keep the single chain in k order, whose rounding stays closest to the reference's sequential
+  // sum -- a different association there is amplified by every layer the value still passes
+  // through (measured: twelve layers take it to the edge of the 1e-4 parity bound).
+  const bool split = g_small_split_on && a->trans_a && !a->trans_b && nw >= 2 && nw <= 8 && tiles * nw <= 4LL * cu_count();
+  p.k_per_wave = split ? 16 * U : a->K;
+#define VITK_SMALL(AV_, BV_)                                                                                  \
+  if (split) hipLaunchKernelGGL((gemm_small_kernel<AV_, BV_, 8>), grid, dim3(64 * nw), 0, st, p);             \
+  else hipLaunchKernelGGL((gemm_small_kernel<AV_, BV_, 1>), grid, dim3(64), 0, st, p);
+  if (av && bv) { VITK_SMALL(true, true) }
+  else if (av) { VITK_SMALL(true, false) }
+  else if (bv) { VITK_SMALL(false, true) }
+  else { VITK_SMALL(false, false) }
+#undef VITK_SMALL
   return check_launch("vitk_gemm_f32/small");
 }
 
 }  // namespace vitk
 
 extern "C" int vitk_gemm_small_enable(int on) {
-  g_small_on = on != 0;
+  g_small_on = on != 0;      // 0: tiled kernel only; 1: the default; 2: small kernel, always one wave per tile
+  g_small_split_on = on != 2;
   return 0;
 }
