@@ -248,6 +248,11 @@ int vitk_sdpa_tile16_enable(int on);
  * key blocks of several heads to the waves of a workgroup: as many heads as it takes for every
  * workgroup to be resident at once, or exactly `on` heads when on >= 2 -- for tests). */
 int vitk_sdpa_bwd_tile16_enable(int on);
+/* Sequences of at most 32 tokens with dh <= 32 and 16-byte-aligned operands (the 5- and 17-token
+ * models) are one 32 x 32 tile per head: one wave does a whole head from registers, forward in
+ * one launch and backward in one launch, four heads per workgroup.  on = 0 keeps them on the
+ * tiled kernels (tests, measurements); the default is on.  Same results to rounding.  Process-wide. */
+int vitk_sdpa_head_kernels_enable(int on);
 int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv, int32_t B, int32_t H, int32_t N,
                   int32_t dh, float scale, float *out, int64_t ld_out, float *stats, vitk_stream_t stream);
 size_t vitk_sdpa_bwd_workspace_bytes(int32_t B, int32_t H, int32_t N);

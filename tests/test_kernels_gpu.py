@@ -43,8 +43,11 @@ def sdpa_path(request, K):
     of three heads to a workgroup (the large-batch configuration: rounds that span two heads, dQ
     accumulated across rounds)."""
     K.sdpa_tile16({"tile16_on": 1, "tile32_only": 0, "tile16_bwd_3_heads_per_workgroup": 3}[request.param])
+    # (tile32_only also keeps sequences of at most 32 tokens off the one-wave-per-head kernels)
+    K.check(K.dll().vitk_sdpa_head_kernels_enable(int(request.param != "tile32_only")))
     yield request.param
     K.sdpa_tile16(True)
+    K.check(K.dll().vitk_sdpa_head_kernels_enable(1))
 
 
 @pytest.fixture
@@ -715,7 +718,9 @@ def heads_of(x, B, N, H, dh, col0):
 @pytest.mark.parametrize("B,H,N,dh,pad", [(2, 3, 197, 64, 0), (3, 8, 5, 12, 0), (2, 6, 17, 32, 0), (1, 2, 256, 64, 0),
                                           (2, 2, 33, 20, 1), (1, 1, 1, 4, 0), (2, 4, 50, 16, 0), (1, 3, 129, 48, 3),
                                           (2, 2, 64, 7, 0), (2, 2, 100, 48, 0), (1, 4, 33, 64, 0), (1, 1, 1, 64, 0),
-                                          (3, 2, 224, 40, 0), (2, 7, 197, 64, 0), (5, 1, 49, 36, 0)])
+                                          (3, 2, 224, 40, 0), (2, 7, 197, 64, 0), (5, 1, 49, 36, 0),
+                                          # one wave per head: a full tile, a ragged head count, tiny heads
+                                          (5, 3, 32, 24, 0), (7, 5, 31, 8, 0), (1, 2, 2, 32, 0)])
 @pytest.mark.parametrize("dk_mode", ["reference", "exact"])
 def test_sdpa_fused_matches_float64(K, B, H, N, dh, pad, dk_mode):
     D, M = H * dh, B * N

@@ -678,6 +678,157 @@ __global__ __launch_bounds__(FT, 1) void sdpa_bwd_fused_kernel(const SdpaParams 
   store_key_grads<DT, true>(p, b, h, key, lh, dk, dv);
 }
 
+// ---- short sequences: one wave per head ---------------------------------------------------------------
+// N <= 32 tokens and dh <= 32 (the 5- and 17-token models): a head is ONE 32 x 32 tile, so a wave
+// does all of it from registers -- row-operand fragments and column operands are read straight
+// from global memory, nothing is staged, no barrier.  Four heads (waves) per workgroup.  The
+// backward forms the score tile in both orientations (transposed for dQ, plain for dK / dV) and
+// needs neither the row-sum pre-pass nor a second launch.
+constexpr int HEAD_WAVES = 4;
+
+// Column operand of a tile: X[row = VITK_ROW_OF(r) + 4 lh][d = li] for r = 0 .. 15 (zero outside).
+__device__ __forceinline__ void load_columns(const float *__restrict__ base, long long ld, int N, int dh, int li, int lh,
+                                             float (&c)[16]) {
+  const bool d_ok = li < dh;
+  const float *col = base + (d_ok ? li : 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = VITK_ROW_OF(r) + 4 * lh;
+    const float t = col[(long long)min(row, N - 1) * ld];
+    c[r] = (d_ok && row < N) ? t : 0.f;
+  }
+}
+
+template <int DHP>
+__global__ __launch_bounds__(64 * HEAD_WAVES) void sdpa_head_fwd_kernel(const SdpaParams p) {
+  constexpr int HALF = DHP / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int bh = blockIdx.x * HEAD_WAVES + wave;
+  if (bh >= p.B * p.H) return;  // (wave-uniform; the kernel has no barrier)
+  const int b = bh / p.H, h = bh % p.H;
+  const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
+  float qf[HALF], kf[HALF], vc[16];
+  load_fragment<DHP, true>(p.q + head, p.ld, li, p.N, p.dh, lh, qf);
+  load_fragment<DHP, true>(p.k + head, p.ld, li, p.N, p.dh, lh, kf);
+  load_columns(p.v + head, p.ld, p.N, p.dh, li, lh, vc);
+  f32x16 s = zero16();  // S^T[key][query = li]
+#pragma unroll
+  for (int jj = 0; jj < HALF; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jj], qf[jj], s, 0, 0, 0);
+  float m = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float x = VITK_ROW_OF(r) + 4 * lh < p.N ? s[r] * p.scale : -INFINITY;
+    s[r] = x;
+    m = fmaxf(m, x);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = __expf(s[r] - m);
+    s[r] = e;
+    l += e;
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] *= inv;
+  if (p.stats != nullptr && lh == 0 && li < p.N) {
+    float *st = p.stats + ((long long)bh * p.N + li) * 2;
+    st[0] = m;
+    st[1] = l;
+  }
+  f32x16 o[1] = {zero16()};  // O^T[d][query = li]
+#pragma unroll
+  for (int r = 0; r < 16; ++r)  // (a step contracts rows VITK_ROW_OF(r) and that + 4: past the sequence both are zero)
+    if (VITK_ROW_OF(r) < p.N) o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r], s[r], o[0], 0, 0, 0);
+  if (li < p.N) store_rows<1, true>(p.out + ((long long)b * p.N + li) * p.ldo + (long long)h * p.dh, o, p.dh, lh);
+}
+
+template <int DHP>
+__global__ __launch_bounds__(64 * HEAD_WAVES) void sdpa_head_bwd_kernel(const SdpaParams p) {
+  constexpr int HALF = DHP / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  // two waves per head, each with half of the work (and of the registers): the even one the query
+  // side, the odd one the key side
+  const int bh = blockIdx.x * (HEAD_WAVES / 2) + (wave >> 1);
+  const bool key_side = wave & 1;
+  if (bh >= p.B * p.H) return;
+  const int b = bh / p.H, h = bh % p.H;
+  const long long head = (long long)b * p.N * p.ld + (long long)h * p.dh;
+  const long long ohead = (long long)b * p.N * p.ldo + (long long)h * p.dh;
+  const bool row_ok = li < p.N;  // li is a query where the lane stands for a column of the transposed tiles, a key otherwise
+  float qf[HALF], kf[HALF], vf[HALF], gf[HALF];
+  load_fragment<DHP, true>(p.q + head, p.ld, li, p.N, p.dh, lh, qf);
+  load_fragment<DHP, true>(p.k + head, p.ld, li, p.N, p.dh, lh, kf);
+  load_fragment<DHP, true>(p.v + head, p.ld, li, p.N, p.dh, lh, vf);
+  load_fragment<DHP, true>(p.dout + ohead, p.ldo, li, p.N, p.dh, lh, gf);
+  float dsum = 0.f, m = 0.f, inv = 0.f;  // of query li
+  {
+    float of[HALF];
+    load_fragment<DHP, true>(p.o + ohead, p.ldo, li, p.N, p.dh, lh, of);
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) dsum += gf[j] * of[j];
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (row_ok) {
+      const float *st = p.stats + ((long long)bh * p.N + li) * 2;
+      m = st[0];
+      inv = 1.0f / st[1];
+    }
+  }
+  // query side: S^T = K Q^T, dP^T = V dO^T ([key][query = li]); dQ^T[d][query] = K^T dS^T
+  if (!key_side) {
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int jj = 0; jj < HALF; ++jj) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jj], qf[jj], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[jj], gf[jj], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = VITK_ROW_OF(r) + 4 * lh < p.N ? __expf(s[r] * p.scale - m) * inv : 0.f;
+      s[r] = (pr * (dp[r] - dsum)) * p.scale;
+    }
+    float kc[16];
+    load_columns(p.k + head, p.ld, p.N, p.dh, li, lh, kc);
+    f32x16 dq[1] = {zero16()};
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (VITK_ROW_OF(r) < p.N) dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[r], s[r], dq[0], 0, 0, 0);
+    if (row_ok) store_rows<1, true>(p.dq + ((long long)b * p.N + li) * p.ldg + (long long)h * p.dh, dq, p.dh, lh);
+    return;
+  }
+  // key side: S = Q K^T, dP = dO V^T ([query][key = li]); dV^T[d][key] = dO^T P, dK^T[d][key] = Q^T dS
+  f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+  for (int jj = 0; jj < HALF; ++jj) {
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[jj], kf[jj], s, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[jj], vf[jj], dp, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {  // the statistics of query VITK_ROW_OF(r) + 4 lh sit in that lane
+    const int query = VITK_ROW_OF(r) + 4 * lh;
+    const float mq = __shfl(m, query, 64), iq = __shfl(inv, query, 64), dq_ = __shfl(dsum, query, 64);
+    const float pr = row_ok ? __expf(s[r] * p.scale - mq) * iq : 0.f;  // (iq = 0 for queries past the sequence)
+    s[r] = pr;
+    dp[r] = (pr * (dp[r] - dq_)) * p.scale;
+  }
+  float gc[16], qc[16];
+  load_columns(p.dout + ohead, p.ldo, p.N, p.dh, li, lh, gc);
+  load_columns(p.q + head, p.ld, p.N, p.dh, li, lh, qc);
+  f32x16 dk[1] = {zero16()}, dv[1] = {zero16()};
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (VITK_ROW_OF(r) < p.N) {
+      dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[r], s[r], dv[0], 0, 0, 0);
+      dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[r], dp[r], dk[0], 0, 0, 0);
+    }
+  if (row_ok) store_key_grads<1, true>(p, b, h, li, lh, dk, dv);
+}
+
+bool g_head_kernels_on = true;
+bool head_kernels_apply(const SdpaParams &p) { return g_head_kernels_on && p.vec && p.N <= 32 && p.dh <= 32; }
+
 template <int DHP, bool VEC>
 int launch_fwd(const SdpaParams &p, int grid, hipStream_t st) {
   const int nkt = (p.N + 31) / 32;
@@ -728,6 +879,11 @@ bool all_vec(std::initializer_list<const void *> ptrs, std::initializer_list<lon
 
 extern "C" {
 
+int vitk_sdpa_head_kernels_enable(int on) {
+  g_head_kernels_on = on != 0;
+  return 0;
+}
+
 int vitk_sdpa_supported(int32_t N, int32_t dh) { return N >= 1 && N <= 256 && dh >= 1 && dh <= 64; }
 
 int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv, int32_t B, int32_t H, int32_t N,
@@ -748,6 +904,12 @@ int vitk_sdpa_fwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   // scalar variant exists once, at the full 64-wide head tile
   if (vitk::sdpa_fwd16_applies(N, dh, p.vec != 0, scale, ld_qkv))  // head dimensions 33..64: 16-row tiles, four heads per workgroup
     return vitk::sdpa_fwd16_launch(q, k, v, ld_qkv, B, H, N, dh, scale, out, ld_out, stats, st);
+  if (head_kernels_apply(p)) {  // a head is one tile: one wave per head
+    const dim3 g((unsigned)((B * H + HEAD_WAVES - 1) / HEAD_WAVES)), blk(64 * HEAD_WAVES);
+    if (dh <= 16) hipLaunchKernelGGL(sdpa_head_fwd_kernel<16>, g, blk, 0, st, p);
+    else hipLaunchKernelGGL(sdpa_head_fwd_kernel<32>, g, blk, 0, st, p);
+    return vitk::check_launch("vitk_sdpa_fwd");
+  }
   if (!p.vec) return launch_fwd<64, false>(p, (int)blocks, st);
   if (dh <= 16) return launch_fwd<16, true>(p, (int)blocks, st);
   if (dh <= 32) return launch_fwd<32, true>(p, (int)blocks, st);
@@ -788,6 +950,12 @@ int vitk_sdpa_bwd(const float *q, const float *k, const float *v, int64_t ld_qkv
   if (vitk::sdpa_bwd16_applies(B, N, dh, p.vec != 0, ld_qkv, ld_out, ld_dqkv))  // 16-row tiles, several heads per workgroup
     return vitk::sdpa_bwd16_launch(q, k, v, ld_qkv, out, dout, ld_out, stats, B, H, N, dh, scale, dk_mode, dq, dk, dv,
                                    ld_dqkv, st);
+  if (head_kernels_apply(p)) {
+    const dim3 g((unsigned)((B * H + HEAD_WAVES / 2 - 1) / (HEAD_WAVES / 2))), blk(64 * HEAD_WAVES);
+    if (dh <= 16) hipLaunchKernelGGL(sdpa_head_bwd_kernel<16>, g, blk, 0, st, p);
+    else hipLaunchKernelGGL(sdpa_head_bwd_kernel<32>, g, blk, 0, st, p);
+    return vitk::check_launch("vitk_sdpa_bwd");
+  }
   if (!p.vec) return launch_bwd<64, false>(p, grid, st);
   if (dh <= 16) return launch_bwd<16, true>(p, grid, st);
   if (dh <= 32) return launch_bwd<32, true>(p, grid, st);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "vitk_dk_reference_scatter": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "vitk_gather_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _p]),
     "vitk_augment_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    "vitk_sdpa_head_kernels_enable": (C.c_int, [C.c_int]),
     "vitk_sdpa_supported": (C.c_int, [_i32, _i32]),
     "vitk_sdpa_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _i64, _p, _p]),
     "vitk_sdpa_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
