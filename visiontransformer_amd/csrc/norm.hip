@@ -191,10 +191,10 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const float *__restrict__ d
 
 // Few rows (at most kSmallRows: the 17- and 5-token models, the CLS rows of the final norm): dx and
 // both parameter gradients in ONE launch, no partials.  Sixteen-wave workgroups; the first
-// `row_blocks` of them give every wave one row of dx, the others own 64 columns each and sum
-// them over all rows (wave w takes rows w, w + 16, ...; the sixteen sums are combined in wave
-// order through LDS).  The column workgroups read dy and x a second time -- from L2 at these
-// sizes -- which costs less than a second launch.
+// `col_blocks` of them own 64 columns each and sum them over all rows (64 row slots per
+// workgroup, combined in slot order through LDS), the others give every wave one row of dx.
+// The column workgroups read dy and x a second time -- from L2 at these sizes -- which costs
+// less than a second launch (640 x 96: 6.8 against 8.2 us per call, tools/bench_ln_small.py).
 constexpr int SM_WAVES = 16;
 constexpr long long kSmallRows = 1024;
 template <int NV>
@@ -202,11 +202,11 @@ __global__ __launch_bounds__(64 * SM_WAVES) void ln_bwd_small_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
     const float *__restrict__ inv_std, const float *__restrict__ gamma, long long rows, int D, long long stride,
     const float *__restrict__ residual, float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    int row_blocks) {
-  __shared__ float sm[2][SM_WAVES][64];
+    int col_blocks) {
+  __shared__ __attribute__((aligned(16))) float sm[2][4 * SM_WAVES][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if ((int)blockIdx.x < row_blocks) {
-    const long long row = blockIdx.x * (long long)SM_WAVES + wv;
+  if ((int)blockIdx.x >= col_blocks) {  // (the column workgroups, the longer ones, come first in the grid)
+    const long long row = ((int)blockIdx.x - col_blocks) * (long long)SM_WAVES + wv;
     if (row >= rows) return;
     const float fD = (float)D, invD = 1.0f / (float)D;
     const float mu = mean[row], inv = inv_std[row];
@@ -248,37 +248,49 @@ __global__ __launch_bounds__(64 * SM_WAVES) void ln_bwd_small_kernel(
     }
     return;
   }
-  const int c = ((int)blockIdx.x - row_blocks) * 64 + lane;
-  constexpr int U = 8;  // rows in flight per thread: the sum is a handful of memory round trips
-  float a[U], b[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) a[u] = 0.f, b[u] = 0.f;
+  // column workgroup: 64 columns; lane (q, rg) takes the column quad 4q .. 4q+3 of the rows
+  // 4 * wave + rg + 64 i -- 16-byte loads, eight rows in flight per lane (640 rows: two round
+  // trips to memory), 64 partial sums per column combined in row-slot order through LDS
+  const int q = lane & 15, slot = wv * 4 + (lane >> 4);
+  const int c = (int)blockIdx.x * 64 + 4 * q;
+  constexpr int U = 8;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   if (c < D) {
-    long long row = wv;
-    for (; row + (U - 1) * SM_WAVES < rows; row += U * SM_WAVES) {
-      float gv[U], xv[U], mu[U], iv[U];
+    for (long long row = slot; row < rows; row += 64 * U) {
+      float4 gv[U], xv[U];
+      float mu[U], iv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const long long r = row + u * SM_WAVES;
-        gv[u] = dy[r * stride + c], xv[u] = x[r * stride + c], mu[u] = mean[r], iv[u] = inv_std[r];
+        const long long r = row + 64 * u < rows ? row + 64 * u : rows - 1;  // (clamped: the loads stay unconditional)
+        gv[u] = *reinterpret_cast<const float4 *>(dy + r * stride + c);
+        xv[u] = *reinterpret_cast<const float4 *>(x + r * stride + c);
+        mu[u] = mean[r], iv[u] = inv_std[r];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) a[u] += gv[u] * ((xv[u] - mu[u]) * iv[u]), b[u] += gv[u];
-    }
-    for (; row < rows; row += SM_WAVES) {
-      const float gv = dy[row * stride + c];
-      a[0] += gv * ((x[row * stride + c] - mean[row]) * inv_std[row]);
-      b[0] += gv;
+      for (int u = 0; u < U; ++u)
+        if (row + 64 * u < rows) {
+          a.x += gv[u].x * ((xv[u].x - mu[u]) * iv[u]); a.y += gv[u].y * ((xv[u].y - mu[u]) * iv[u]);
+          a.z += gv[u].z * ((xv[u].z - mu[u]) * iv[u]); a.w += gv[u].w * ((xv[u].w - mu[u]) * iv[u]);
+          b.x += gv[u].x; b.y += gv[u].y; b.z += gv[u].z; b.w += gv[u].w;
+        }
     }
   }
-  sm[0][wv][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  sm[1][wv][lane] = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
+  *reinterpret_cast<float4 *>(&sm[0][slot][4 * q]) = a;
+  *reinterpret_cast<float4 *>(&sm[1][slot][4 * q]) = b;
   __syncthreads();
-  if (wv < 2 && c < D) {  // wave 0: dgamma, wave 1: dbeta
-    float t = 0.f;
+  if (threadIdx.x < 128) {  // threads 0..63: dgamma, 64..127: dbeta
+    const int which = threadIdx.x >> 6, col = (int)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (col < D) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-    for (int w = 0; w < SM_WAVES; ++w) t += sm[wv][w][lane];
-    (wv == 0 ? dgamma : dbeta)[c] = t;
+      for (int k = 0; k < 64; k += 4) {
+        t0 += sm[which][k][threadIdx.x & 63];
+        t1 += sm[which][k + 1][threadIdx.x & 63];
+        t2 += sm[which][k + 2][threadIdx.x & 63];
+        t3 += sm[which][k + 3][threadIdx.x & 63];
+      }
+      (which == 0 ? dgamma : dbeta)[col] = (t0 + t1) + (t2 + t3);
+    }
   }
 }
 
@@ -510,7 +522,7 @@ int vitk_layernorm_bwd(const float *dy, const float *x, const float *mean, const
     const int row_blocks = (int)((rows + SM_WAVES - 1) / SM_WAVES), col_blocks = (int)((D + 63) / 64);
     const dim3 sgrid((unsigned)(row_blocks + col_blocks)), sblk(64 * SM_WAVES);
 #define LNS(NV) hipLaunchKernelGGL((ln_bwd_small_kernel<NV>), sgrid, sblk, 0, st, dy, x, mean, inv_std, gamma, \
-                                   (long long)rows, (int)D, (long long)row_stride, residual, dx, dgamma, dbeta, row_blocks)
+                                   (long long)rows, (int)D, (long long)row_stride, residual, dx, dgamma, dbeta, col_blocks)
     switch (nv) {
       case 1: LNS(1); break;
       case 2: LNS(2); break;
