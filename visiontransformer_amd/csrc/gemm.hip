@@ -750,6 +750,12 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
     // a small remainder after whole rounds is cut off and run on 64-wide tiles anyway (tail round)
     double e128 = (t128 >= slots && t128 % slots <= 128) ? 0.98 : fill(t128);
     if (t128 < 2 * cus) e128 *= 0.9;  // fewer than two workgroups per CU: latencies show
+    // between one and two rounds of resident workgroups the second round is what counts
+    // (M = 50 432, N = 384: 1182 tiles = 1.54 rounds, 110 vs 117 TFLOP/s at K = 384, 125 vs 129 at K = 768)
+    if (t128 > slots && t128 < 2 * slots && !(t128 % slots <= 128)) {
+      const double two_rounds = (double)t128 / (double)(2 * slots);
+      if (two_rounds < e128) e128 = two_rounds;
+    }
     // a short contraction: the 128-wide tile's longer fill and store phases weigh more than its
     // better operand reuse (M = 50 432, N = 768, K = 192: 103 vs 108 TFLOP/s; no difference from K = 384 on)
     if (a->K <= 256) e128 *= 0.93;
