@@ -63,6 +63,18 @@ int vith_comm_init(int rank, int world, const void *id128);
 int vith_comm_init_file(int rank, int world, const char *path, int timeout_s);
 int vith_comm_init_external(int rank, int world, vith_allreduce_fn allreduce, vith_broadcast_fn broadcast, void *user,
                             int stream_ordered);
+/* The file exchange of vith_comm_init_file on its own (host code only, no RCCL, no GPU): rank 0
+ * passes the 128-byte id in id128, the other ranks receive it there.  The ranks confirm each other
+ * with per-process random nonces (files <path>, <path>.req<r>, <path>.ack<r>, all created
+ * exclusively with mode 0600 and removed by rank 0 at the end), so whatever an earlier, failed
+ * launch left at the same path is never taken for this launch's id. */
+int vith_comm_exchange_id_file(int rank, int world, const char *path, int timeout_s, void *id128);
+/* Measurement of the part of the exchange that backward does not hide: while on, every step records
+ * a HIP-event pair -- compute stream, when the last bucket closes (= behind the last backward
+ * kernel); side stream, behind that bucket's all-reduce.  vith_comm_exposed_ms synchronises, writes
+ * the sum of the pairs' elapsed times since the last call and returns their number (-1 on error). */
+int vith_comm_timing(int on);
+int64_t vith_comm_exposed_ms(double *total_ms);
 int vith_comm_destroy(void);
 /* The bucket rule on its own (pure host code): stage s finalises [stage_offset[s], +stage_count[s])
  * of the gradient arena, slices adjacent and descending; out3 receives {last stage, offset, count}
@@ -175,6 +187,10 @@ int vith_fit_reference_defaults(vith_model m, const float *x, const float *y_one
                                 const float *y_test_onehot, uint64_t n_test, int epochs, uint64_t batch_size,
                                 float lr_init, float weight_decay, float warmup_frac, float *history);
 uint64_t vith_next_seed(void);
+/* wall time in milliseconds of the training part of every epoch the last vith_fit* call ran (the
+ * batches of Trainer::train_epoch until the device has finished them; evaluation excluded);
+ * returns the number of epochs, writes at most `capacity` values */
+uint64_t vith_last_fit_epoch_ms(double *ms, uint64_t capacity);
 /* vith_fit (no augmentation) with the checkpoint extensions of TrainerConfig, none of which the
  * reference has (it keeps optimizer state in memory only, src/optimizers/Adam.cpp:22-25):
  *   best_weights_path  after an epoch whose test accuracy is a new best AND above that epoch's

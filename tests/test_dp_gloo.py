@@ -25,7 +25,7 @@ B_GLOBAL, STEPS = 8, 3
 
 
 class OracleEngine:
-    """CPU stand-in: same protocol as dp.HostEngine, gradients from the oracle at stage 0."""
+    """CPU stand-in for the staged trainer (forward, backward stages, update): gradients from the oracle at stage 0."""
 
     def __init__(self, seed):
         self.O = V.oracle()

@@ -122,6 +122,13 @@ def _rank_main(rank, world, port, outdir):
     m, t, got = run_steps(host, make, mine, xs, ys, rank * B_RANK, (rank + 1) * B_RANK)
     assert t.num_buckets() >= 2
     np.save(os.path.join(outdir, f"steps_r{rank}.npy"), got)
+    # a training state written by rank 0 and loaded by every rank: each keeps a dropout stream of its own
+    state = os.path.join(outdir, "dp_state.bin")
+    if rank == 0:
+        t.save_state(state)
+    dist.barrier()
+    t.load_state(state)
+    np.save(os.path.join(outdir, f"drop_r{rank}.npy"), np.array(host.dropout_state(), dtype=np.uint64))
     # Trainer::train, every rank holding the whole data set and taking its slice of each batch
     x, y, xt, yt = fit_inputs()
     f = FIT
@@ -173,6 +180,8 @@ def test_two_ranks_on_one_gpu_match_one_rank_on_the_whole_batch(H, tmp_path, mon
             off += k
 
     same_training(a, want, 6e-3, "steps")
+    d0, d1 = np.load(tmp_path / "drop_r0.npy"), np.load(tmp_path / "drop_r1.npy")
+    assert d0[0] != d1[0] and d0[1] == d1[1], (d0, d1)  # resumed ranks still draw different masks, same position
     fa, fb = np.load(tmp_path / "fit_r0.npy"), np.load(tmp_path / "fit_r1.npy")
     np.testing.assert_array_equal(fa, fb)
     np.testing.assert_array_equal(np.load(tmp_path / "hist_r0.npy"), np.load(tmp_path / "hist_r1.npy"))
@@ -185,3 +194,26 @@ def test_two_ranks_on_one_gpu_match_one_rank_on_the_whole_batch(H, tmp_path, mon
     got_hist = np.load(tmp_path / "hist_r0.npy")
     np.testing.assert_allclose(got_hist[:, [0, 2]], hist[:, [0, 2]], rtol=1e-4)
     np.testing.assert_allclose(got_hist[:, [1, 3]], hist[:, [1, 3]], atol=1e-6)
+
+
+def test_bench_starts_its_ranks_itself_and_reports_the_exchange(tmp_path):
+    """`python bench.py --gpus 1 --force-collectives` with no launcher around it: the parent starts the
+    rank as a child before touching the GPU; the child joins the host layer's RCCL communicator
+    (its only one; a CPU gloo group carries the id) and issues every bucket's all-reduce."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collectives",
+                        "--workload", "blood_p7", "--batch", "64", "--steps", "4", "--warmup", "2", "--bucket-mb", "0.25",
+                        "--no-cpu-baseline", "--launch-timeout", "100"],
+                       env=env, capture_output=True, text=True, timeout=110, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1
+    assert len(out["per_rank_ms_per_step"]) == 1 and 0 < out["per_rank_ms_per_step"][0] <= out["ms_per_step"] * 1.001
+    assert out["exposed_comm_ms_per_step"] >= 0 and out["exposed_comm_ms_per_step"] < out["ms_per_step"]
+    assert "gradient buckets" in out["config"]["parallelism"]
+    assert np.isfinite(out["config"]["final_loss"]) and out["value"] > 0

@@ -509,6 +509,33 @@ def test_im2col_mode_reads_true_patches_and_exact_dk_matches_autograd(H):
     close(dimg, xt.grad.numpy(), GRAD_TOL, "image gradient vs autograd")
 
 
+def test_backward_returns_the_image_gradient_after_a_trainer_has_used_the_model(H, tmp_path, monkeypatch):
+    """Trainer::train drops the image gradient (src/model/Trainer.cpp:212) and so never forms it; the
+    model's own backward() -- Layer::backward of the reference -- must return it all the same, before
+    and after any number of Trainers (whole fits and single steps) have worked on the model."""
+    monkeypatch.chdir(tmp_path)
+    cfgd = V.TINY
+    ocfg = V.Cfg.make(**cfgd)
+    K = ocfg.num_classes
+    m = H.Model(hcfg(H, cfgd))
+    m.set_params(V.init_params(ocfg, 8))
+    x = V.rng_normal(9, 12, 1, 28, 28)
+    y = V.onehot(np.arange(12) % K, K)
+    m.fit(x, y, x[:4], y[:4], 1, 4, 1e-3, 1e-4, 0.1)
+    t = H.Trainer(m)
+    t.train_step(dev(x[:4]), dev(y[:4]), 1e-3)
+    prm = m.get_params()
+    dlogits = V.rng_normal(10, 4, K) * 0.1
+    m.forward(dev(x[:4]), training=True)
+    got = host_np(m.backward_image(dev(dlogits)))
+    fresh = H.Model(hcfg(H, cfgd))  # never seen by a Trainer
+    fresh.set_params(prm)
+    fresh.forward(dev(x[:4]), training=True)
+    want = host_np(fresh.backward_image(dev(dlogits)))
+    assert np.abs(want).max() > 0
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("name,B", [("C1", 128), ("C2", 64), ("C3", 3), ("C4", 1), ("C5", 2)])
 def test_model_vs_oracle_at_baseline_shapes(H, name, B):
     """The reference's own configurations at their full batch, and the 224x224 ViT-Ti / ViT-S

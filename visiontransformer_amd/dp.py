@@ -25,8 +25,11 @@ from ``Trainer`` alone.  This module is the launcher side for Python callers:
   exchange through host memory and a CPU process group, one collective at a time;
 * :class:`NativeDataParallel` -- the step driver on top of either.
 
-:class:`DataParallel` is the same bucketing and ordering written against an abstract engine; it is
-what the CPU-only (gloo, world size 2) tests exercise with a CPU stand-in engine.
+:class:`DataParallel` is the same bucketing and ordering written against an abstract engine with
+HOST tensors; it is what the CPU-only (gloo, world size 2) tests exercise with a CPU stand-in
+engine.  It refuses device tensors: several asynchronous gloo collectives on device memory, with
+two processes sharing one GPU, is a combination that has hung, and the device path above
+(RCCL on the library's side stream) replaces it.
 """
 import torch
 import torch.distributed as dist
@@ -104,29 +107,7 @@ class NativeDataParallel:
         t.update(lr, 1.0)        # waits for the buckets on the compute stream, then Adam
 
 
-# ----------------------------------------------------------- generic engine path (CPU tests)
-class HostEngine:
-    """Adapter from visiontransformer_amd.host (Model + Trainer) to the engine protocol."""
-
-    def __init__(self, model, trainer):
-        self.model, self.trainer = model, trainer
-        self.num_stages = trainer.num_stages
-        self.params = device_span(model.params_device(), model.n)
-        self.grads = device_span(model.grads_device(), model.n)
-
-    def stage_grad_range(self, s):
-        return self.trainer.stage_grad_range(s)
-
-    def step_forward(self, x, y, grad_batch):
-        self.trainer.step_forward(x, y, grad_batch)
-
-    def backward_stage(self, s):
-        self.trainer.backward_stage(s)
-
-    def update(self, lr, grad_scale):
-        self.trainer.update(lr, grad_scale)
-
-
+# ------------------------------------------------- the same rule against an abstract engine
 def plan_buckets(ranges, bucket_bytes):
     """Merge the per-stage gradient slices (in the order backward finalises them) into buckets.
 
@@ -155,10 +136,12 @@ def plan_buckets(ranges, bucket_bytes):
 class DataParallel:
     """``engine`` is any object with ``num_stages``, ``stage_grad_range(s) -> (offset, count)``,
     ``step_forward(x, y, grad_batch)``, ``backward_stage(s)``, ``update(lr, grad_scale)`` and the
-    flat ``grads`` / ``params`` torch tensors."""
+    flat ``grads`` / ``params`` torch tensors in host memory."""
 
     def __init__(self, engine, group=None, bucket_bytes=25 << 20, always_reduce=False):
         """always_reduce: issue the collectives even with a single rank (they are then identities)."""
+        if engine.grads.is_cuda or engine.params.is_cuda:
+            raise ValueError("dp.DataParallel works on host tensors; device models use NativeDataParallel")
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.reduce = self.world > 1 or (always_reduce and dist.is_initialized())

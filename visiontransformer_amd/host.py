@@ -50,6 +50,10 @@ SIGNATURES = {
     "vith_comm_init": (_int, [_int, _int, _p]),
     "vith_comm_init_file": (_int, [_int, _int, C.c_char_p, _int]),
     "vith_comm_init_external": (_int, [_int, _int, _p, _p, _p, _int]),
+    "vith_comm_exchange_id_file": (_int, [_int, _int, C.c_char_p, _int, _p]),
+    "vith_comm_timing": (_int, [_int]),
+    "vith_comm_exposed_ms": (_i64, [C.POINTER(C.c_double)]),
+    "vith_last_fit_epoch_ms": (_u64, [C.POINTER(C.c_double), _u64]),
     "vith_comm_destroy": (_int, []),
     "vith_plan_buckets": (_i64, [_pu, _pu, _u64, _u64, _pu, _u64]),
     "vith_comm_rank": (_int, []),
@@ -188,6 +192,34 @@ def comm_init(rank, world, unique_id):
 
 def comm_init_file(rank, world, path, timeout_s=120):
     _check(dll().vith_comm_init_file(rank, world, os.fsencode(path), timeout_s))
+
+
+def comm_exchange_id_file(rank, world, path, unique_id=None, timeout_s=120):
+    """The id exchange of comm_init_file alone (no RCCL, no GPU): rank 0 passes the id, every rank
+    returns it."""
+    buf = C.create_string_buffer(unique_id if rank == 0 else b"", 128)
+    _check(dll().vith_comm_exchange_id_file(rank, world, os.fsencode(path), timeout_s, buf))
+    return buf.raw
+
+
+def comm_timing(on):
+    _check(dll().vith_comm_timing(int(bool(on))))
+
+
+def comm_exposed_ms():
+    """(sum of the per-step exposed exchange times in ms, number of steps) since the last call."""
+    total = C.c_double()
+    n = dll().vith_comm_exposed_ms(C.byref(total))
+    if n < 0:
+        raise HostError(dll().vith_last_error().decode(errors="replace"))
+    return total.value, int(n)
+
+
+def last_fit_epoch_ms():
+    n = dll().vith_last_fit_epoch_ms(None, 0)
+    out = (C.c_double * max(int(n), 1))()
+    dll().vith_last_fit_epoch_ms(out, n)
+    return [out[i] for i in range(int(n))]
 
 
 def comm_init_external(rank, world, allreduce, broadcast, stream_ordered):

@@ -44,13 +44,20 @@ typedef int (*BroadcastFn)(float *dev, uint64_t count, int root, void *stream, v
 void comm_unique_id(void *id128);
 // Collective over all ranks: joins the RCCL communicator on the current device.
 void comm_init_rccl(int rank, int world, const void *id128);
-// The same with the id exchanged through a file: rank 0 writes `path`, the others wait for it
-// (at most timeout_s seconds) and read it.  Rank 0 removes the file once everyone has joined.
+// The same with the id exchanged through files next to `path` (see comm_exchange_id_file); every
+// rank waits at most timeout_s seconds for the others.
 void comm_init_rccl_file(int rank, int world, const std::string &path, int timeout_s = 120);
+// The exchange on its own (pure host code, no RCCL): rank 0 passes the id in id128, the others
+// receive it there.  Ranks confirm each other with per-process random nonces, so files that an
+// earlier, failed launch left at the same path are never taken for this launch's; all files are
+// created exclusively with mode 0600 and symbolic links or other users' files are refused.
+void comm_exchange_id_file(int rank, int world, const std::string &path, int timeout_s, void *id128);
 // Reads RANK / WORLD_SIZE / LOCAL_RANK (the variables torchrun and most launchers set); with
 // WORLD_SIZE > 1 selects device LOCAL_RANK and joins through the file VIT_COMM_ID_FILE (default
-// /tmp/vit_comm_<MASTER_ADDR>_<MASTER_PORT>.id).  Returns false (and does nothing) when WORLD_SIZE
-// is unset or 1, or a communicator already exists.
+// /tmp/vit_comm_<uid>_<MASTER_ADDR>_<MASTER_PORT>_<VIT_COMM_RUN_ID or TORCHELASTIC_RUN_ID>.id).
+// Must run before this process creates its first tensor (the device cannot change afterwards:
+// vit::init throws).  Returns false (and does nothing) when WORLD_SIZE is unset or 1, or a
+// communicator already exists.
 bool comm_init_from_env();
 // Transport provided by the caller.
 void comm_init_external(int rank, int world, AllReduceFn allreduce, BroadcastFn broadcast, void *user,
@@ -63,6 +70,14 @@ int comm_world();  // 1 without a communicator
 // Raw collectives on the compute stream (parameters at start-up, scalar metrics).
 void comm_broadcast(float *dev, size_t count, int root);
 void comm_allreduce(float *dev, size_t count);
+
+// Measurement of the part of the gradient exchange that backward does not hide.  While on, every
+// step records one HIP-event pair: on the compute stream when the step's last bucket closes (the
+// last backward kernel has been enqueued) and on the side stream behind that bucket's all-reduce.
+// comm_exposed_ms waits for both streams, adds up the elapsed times of the pairs recorded since the
+// last call into *total_ms and returns their number.  Stream-ordered transports only.
+void comm_timing(bool on);
+size_t comm_exposed_ms(double *total_ms);
 
 // Bucketed, overlapped all-reduce of one model's gradient arena (see the header comment).
 class GradientReducer {

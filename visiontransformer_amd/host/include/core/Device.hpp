@@ -16,8 +16,11 @@ namespace vit {
 void check(int rc, const char *what);
 void hip_check(int hip_error, const char *what);
 
-// Select the device (default 0) -- called implicitly on first use.
+// Select the device (default 0) -- called implicitly on first use.  Selecting another device
+// later is refused (std::runtime_error) once this process holds device memory: tensors, the
+// workspace and cached blocks stay on the device they were allocated on.
 void init(int device = 0);
+int current_device();  // -1 before the first use
 // Use an existing hipStream_t (e.g. the caller framework's current stream) instead of the
 // library's own; nullptr selects the default (null) stream.
 void set_stream(void *hip_stream);
@@ -53,6 +56,10 @@ void set_dropout_state(uint64_t seed, uint64_t offset);
 // ranks apply different masks to their different samples.  The seed reported by
 // get_dropout_state and passed to the kernels is that effective key.
 void set_dropout_rank(int rank);
+// The same position with the UNSALTED seed: what a training state file holds, so that every rank
+// that loads it re-applies its own salt and keeps drawing masks of its own.
+void get_dropout_base_state(uint64_t *seed_out, uint64_t *offset_out);
+void set_dropout_base_state(uint64_t seed, uint64_t offset);
 // Replay of recorded dropout draws: while a buffer is set, every training-mode Dropout forward
 // takes its `count` factors (0 or 1/(1-rate)) from it, in call order, instead of the device
 // stream -- this repeats a run whose masks were recorded elsewhere (e.g. by the reference, whose

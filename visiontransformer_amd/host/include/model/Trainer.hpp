@@ -82,6 +82,9 @@ public:
   float bestTestAccuracy() const { return best_test_acc; }
   // {train loss, train accuracy, test loss, test accuracy} of every epoch train() has run
   const std::vector<std::array<float, 4>> &history() const { return epoch_history; }
+  // wall time of each epoch's training part (train_epoch until its last kernel has finished,
+  // evaluation excluded), in milliseconds
+  const std::vector<double> &epochTrainMs() const { return train_ms; }
   CrossEntropy &getLoss() { return loss_fn; }
 
 private:
@@ -100,6 +103,7 @@ private:
   long long total_steps = 0;
   float best_test_acc = 0.0f;
   std::vector<std::array<float, 4>> epoch_history;
+  std::vector<double> train_ms;
   bool quiet = false;
   std::unique_ptr<vit::GradientReducer> reducer;  // set when a communicator exists
   Tensor metrics;                                 // {loss sum, correct} exchanged per step

@@ -83,8 +83,8 @@ public:
   void backwardBegin(const Tensor &outputGradient);
   void backwardStage(size_t stage);
   // backward() returns the image gradient {B,C,H,W} (src/model/VisionTransformer.cpp:68); the staged
-  // form used by training steps skips it unless asked.  setDiscardInputGradient(true) lets a
-  // caller of backward() that drops the result (Trainer, src/model/Trainer.cpp:212) skip it too.
+  // form used by training steps (which drop it, src/model/Trainer.cpp:212) skips it unless asked
+  // with setStageInputGradient(true).
   // Process-wide switch (default on): let the last encoder block and the final norm work on the CLS
   // token only -- the only token the classification head reads (src/model/VisionTransformer.cpp:
   // 27-37) and the only one whose gradient is non-zero (:49-56).  Logits, loss, every parameter
@@ -93,7 +93,6 @@ public:
   static void setFirstTokenTail(bool on);
   static bool firstTokenTail();
   void setStageInputGradient(bool want) { wantInputGradient = want; }
-  void setDiscardInputGradient(bool discard) { discardInputGradient = discard; }
   // [offset, offset+count) of the gradient arena finalised by `stage`
   void stageGradientRange(size_t stage, size_t *offset, size_t *count) const;
   // token stream after embeddings / each block / final norm of the last forward ((L+2) tensors),
@@ -122,7 +121,7 @@ private:
   bool trace = false;
   bool tailForward = false;  // the last training forward used the first-token form of the last block
   bool normFirstOnly = false;  // ... or the dense last block with the final norm on the CLS rows only
-  bool wantInputGradient = false, discardInputGradient = false;
+  bool wantInputGradient = false;
   std::vector<Tensor> traceActs, traceGrads;
 };
 

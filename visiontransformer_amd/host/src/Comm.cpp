@@ -4,16 +4,19 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>  // declarations only: the library is loaded with dlopen
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
-#include <fstream>
+#include <random>
 #include <thread>
+#include <vector>
 
 #include "core/Device.hpp"
 #include "model/VisionTransformer.hpp"
@@ -42,6 +45,9 @@ struct State {
   void *user = nullptr;
   bool stream_ordered = true;
   hipStream_t side = nullptr;
+  // exposed-exchange timing (comm_timing): per step one event pair around the tail of the exchange
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> samples;
 };
 
 State &C() {
@@ -102,8 +108,13 @@ void activate(int rank, int world) {
   if (rank < 0 || world < 1 || rank >= world) throw std::invalid_argument("comm_init: rank/world out of range");
   s.rank = rank;
   s.world = world;
-  if (s.stream_ordered && !s.side)
-    hip_check(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking), "hipStreamCreate(side stream)");
+  if (s.stream_ordered && !s.side) {
+    // highest priority the device offers: a collective's few workgroups should be scheduled ahead
+    // of the next backward kernel's thousands instead of queueing behind them
+    int least = 0, greatest = 0;
+    hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    hip_check(hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, greatest), "hipStreamCreate(side stream)");
+  }
   // every rank draws different dropout masks for its different samples
   set_dropout_rank(rank);
   s.active = true;
@@ -138,36 +149,131 @@ void comm_init_rccl(int rank, int world, const void *id128) {
   activate(rank, world);
 }
 
-void comm_init_rccl_file(int rank, int world, const std::string &path, int timeout_s) {
-  char id[kCommIdBytes];
-  if (rank == 0) {
-    comm_unique_id(id);
-    const std::string tmp = path + ".tmp";
-    {
-      std::ofstream out(tmp, std::ios::binary | std::ios::trunc);
-      out.write(id, sizeof id);
-      if (!out) throw std::runtime_error("comm_init_rccl_file: cannot write " + tmp);
-    }
-    if (std::rename(tmp.c_str(), path.c_str()) != 0)
-      throw std::runtime_error("comm_init_rccl_file: cannot rename " + tmp + " to " + path);
-  } else {
-    // wait for a file that rank 0 of THIS launch wrote: one left behind by an earlier run that
-    // died before joining is older than any launcher takes to start its ranks
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      struct stat st;
-      if (stat(path.c_str(), &st) == 0 && st.st_size == (off_t)sizeof id && std::time(nullptr) - st.st_mtime < 600) {
-        std::ifstream in(path, std::ios::binary);
-        in.read(id, sizeof id);
-        if (in) break;
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s))
-        throw std::runtime_error("comm_init_rccl_file: timed out waiting for " + path);
-      std::this_thread::sleep_for(std::chrono::milliseconds(20));
-    }
+// ---- id exchange through the file system ----------------------------------------------------------
+// Files are created under a temporary name with O_EXCL | O_NOFOLLOW and mode 0600, then renamed;
+// readers refuse symbolic links and files of another user.
+namespace {
+
+constexpr char kIdMagic[8] = {'V', 'I', 'T', 'C', 'O', 'M', 'M', '2'};
+
+void write_file_atomically(const std::string &path, const void *data, size_t bytes) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  (void)unlink(tmp.c_str());
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (fd < 0) throw std::runtime_error("comm id exchange: cannot create " + tmp + ": " + std::strerror(errno));
+  const ssize_t w = write(fd, data, bytes);
+  const int rc = close(fd);
+  if (w != (ssize_t)bytes || rc != 0 || std::rename(tmp.c_str(), path.c_str()) != 0) {
+    (void)unlink(tmp.c_str());
+    throw std::runtime_error("comm id exchange: cannot write " + path);
   }
+}
+
+// Reads exactly `bytes` bytes of a regular file owned by this user; false when it is not (yet) there.
+bool read_own_file(const std::string &path, void *data, size_t bytes) {
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && st.st_size == (off_t)bytes;
+  if (ok) ok = read(fd, data, bytes) == (ssize_t)bytes;
+  close(fd);
+  return ok;
+}
+
+struct Published {  // what rank 0 writes to `path`
+  char magic[8];
+  uint64_t world;
+  char id[kCommIdBytes];
+  // followed by world x uint64 nonces (slot 0: rank 0's own)
+};
+
+}  // namespace
+
+// Every rank draws a fresh random nonce.  Rank r > 0 announces its own in <path>.req<r>; rank 0
+// publishes {id, its nonce, the nonces it has seen} in <path> and publishes again whenever an
+// announcement changes; a rank accepts a published file only if it carries ITS nonce of THIS
+// process, and then confirms with {its nonce, rank 0's nonce} in <path>.ack<r>; rank 0 returns once
+// every rank has confirmed the nonces it published last.  Files that an earlier launch left behind
+// (any of the three kinds) carry other nonces and are ignored or overwritten, whenever they were
+// written.
+void comm_exchange_id_file(int rank, int world, const std::string &path, int timeout_s, void *id128) {
+  if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("comm_exchange_id_file: rank/world out of range");
+  if (world == 1) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto expired = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s); };
+  auto nap = [] { std::this_thread::sleep_for(std::chrono::milliseconds(10)); };
+  const size_t pub_bytes = sizeof(Published) + (size_t)world * sizeof(uint64_t);
+  std::vector<char> buf(pub_bytes);
+  auto *pub = reinterpret_cast<Published *>(buf.data());
+  auto *nonces = reinterpret_cast<uint64_t *>(buf.data() + sizeof(Published));
+  std::random_device rd;
+  uint64_t nonce = 0;
+  while (nonce == 0) nonce = ((uint64_t)rd() << 32) ^ rd() ^ ((uint64_t)getpid() << 17);
+  if (rank != 0) {
+    const std::string req = path + ".req" + std::to_string(rank), ack = path + ".ack" + std::to_string(rank);
+    (void)unlink(ack.c_str());
+    write_file_atomically(req, &nonce, sizeof nonce);
+    for (;;) {
+      if (read_own_file(path, buf.data(), pub_bytes) && std::memcmp(pub->magic, kIdMagic, 8) == 0 &&
+          pub->world == (uint64_t)world && nonces[rank] == nonce)
+        break;
+      if (expired()) {
+        (void)unlink(req.c_str());
+        throw std::runtime_error("comm_exchange_id_file: timed out waiting for rank 0 to publish " + path);
+      }
+      nap();
+    }
+    std::memcpy(id128, pub->id, kCommIdBytes);
+    const uint64_t confirm[2] = {nonce, nonces[0]};
+    write_file_atomically(ack, confirm, sizeof confirm);
+    return;
+  }
+  std::vector<uint64_t> seen(world, 0), published(world, 0);
+  seen[0] = nonce;
+  bool have_published = false;
+  (void)unlink(path.c_str());
+  for (;;) {
+    bool all = true;
+    for (int r = 1; r < world; ++r) {
+      uint64_t n = 0;
+      if (read_own_file(path + ".req" + std::to_string(r), &n, sizeof n) && n != 0) seen[r] = n;
+      all = all && seen[r] != 0;
+    }
+    if (all && (!have_published || seen != published)) {
+      std::memcpy(pub->magic, kIdMagic, 8);
+      pub->world = (uint64_t)world;
+      std::memcpy(pub->id, id128, kCommIdBytes);
+      for (int r = 0; r < world; ++r) nonces[r] = seen[r];
+      write_file_atomically(path, buf.data(), pub_bytes);
+      published = seen;
+      have_published = true;
+    }
+    if (have_published) {
+      bool confirmed = true;
+      for (int r = 1; r < world && confirmed; ++r) {
+        uint64_t c[2] = {0, 0};
+        confirmed = read_own_file(path + ".ack" + std::to_string(r), c, sizeof c) && c[0] == published[r] && c[1] == nonce;
+      }
+      if (confirmed) break;
+    }
+    if (expired()) {
+      (void)unlink(path.c_str());
+      throw std::runtime_error("comm_exchange_id_file: timed out waiting for the other ranks at " + path);
+    }
+    nap();
+  }
+  (void)unlink(path.c_str());
+  for (int r = 1; r < world; ++r) {
+    (void)unlink((path + ".req" + std::to_string(r)).c_str());
+    (void)unlink((path + ".ack" + std::to_string(r)).c_str());
+  }
+}
+
+void comm_init_rccl_file(int rank, int world, const std::string &path, int timeout_s) {
+  char id[kCommIdBytes] = {0};
+  if (rank == 0) comm_unique_id(id);
+  comm_exchange_id_file(rank, world, path, timeout_s, id);
   comm_init_rccl(rank, world, id);
-  if (rank == 0) std::remove(path.c_str());  // ncclCommInitRank returns once every rank has joined
 }
 
 bool comm_init_from_env() {
@@ -179,7 +285,8 @@ bool comm_init_from_env() {
   init(local);
   std::string path = env_or("VIT_COMM_ID_FILE", "");
   if (path.empty())
-    path = std::string("/tmp/vit_comm_") + env_or("MASTER_ADDR", "local") + "_" + env_or("MASTER_PORT", "0") + ".id";
+    path = std::string("/tmp/vit_comm_") + std::to_string((long)geteuid()) + "_" + env_or("MASTER_ADDR", "local") + "_" +
+           env_or("MASTER_PORT", "0") + "_" + env_or("VIT_COMM_RUN_ID", env_or("TORCHELASTIC_RUN_ID", "run")) + ".id";
   comm_init_rccl_file(rank, world, path);
   return true;
 }
@@ -206,6 +313,12 @@ void comm_destroy() {
     (void)hipStreamDestroy(s.side);
     s.side = nullptr;
   }
+  for (auto &p : s.samples) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  s.samples.clear();
+  s.timing = false;
   if (s.comm) {
     (void)s.rccl.commDestroy(s.comm);
     s.comm = nullptr;
@@ -233,6 +346,31 @@ void comm_allreduce(float *dev, size_t count) {
   State &s = C();
   if (!s.active || count == 0) return;
   if (s.ar(dev, count, stream(), s.user)) throw std::runtime_error("comm_allreduce: transport failure");
+}
+
+void comm_timing(bool on) {
+  State &s = C();
+  if (on && !(s.active && s.stream_ordered))
+    throw std::runtime_error("comm_timing: needs a stream-ordered communicator");
+  s.timing = on;
+}
+
+size_t comm_exposed_ms(double *total_ms) {
+  State &s = C();
+  synchronize();
+  if (s.side) hip_check(hipStreamSynchronize(s.side), "hipStreamSynchronize(side)");
+  double sum = 0.0;
+  for (auto &p : s.samples) {
+    float ms = 0.0f;
+    hip_check(hipEventElapsedTime(&ms, p.first, p.second), "hipEventElapsedTime(exchange tail)");
+    sum += ms;
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  const size_t n = s.samples.size();
+  s.samples.clear();
+  if (total_ms) *total_ms = sum;
+  return n;
 }
 
 // ------------------------------------------------------------------------- GradientReducer
@@ -291,10 +429,24 @@ void GradientReducer::afterStage(size_t stage) {
     float *g = model.arena().grads()->dev_write() + plan[i].offset;
     hipStream_t compute = static_cast<hipStream_t>(stream());
     if (s.stream_ordered) {
+      // the step's last bucket closes with the last backward kernel: from there to the end of its
+      // all-reduce (the side stream runs the buckets in order) the compute stream has nothing to
+      // run -- the part of the exchange that backward does not hide
+      const bool sample = s.timing && i + 1 == plan.size();
+      hipEvent_t t_ready = nullptr, t_done = nullptr;
+      if (sample) {
+        hip_check(hipEventCreate(&t_ready), "hipEventCreate");
+        hip_check(hipEventCreate(&t_done), "hipEventCreate");
+        hip_check(hipEventRecord(t_ready, compute), "hipEventRecord(exchange tail begin)");
+      }
       hip_check(hipEventRecord(static_cast<hipEvent_t>(ready[i]), compute), "hipEventRecord(bucket ready)");
       hip_check(hipStreamWaitEvent(s.side, static_cast<hipEvent_t>(ready[i]), 0), "hipStreamWaitEvent(side)");
       if (s.ar(g, plan[i].count, s.side, s.user)) throw std::runtime_error("GradientReducer: all-reduce failed");
       hip_check(hipEventRecord(static_cast<hipEvent_t>(done[i]), s.side), "hipEventRecord(bucket done)");
+      if (sample) {
+        hip_check(hipEventRecord(t_done, s.side), "hipEventRecord(exchange tail end)");
+        s.samples.emplace_back(t_ready, t_done);
+      }
     } else {
       if (s.ar(g, plan[i].count, compute, s.user)) throw std::runtime_error("GradientReducer: all-reduce failed");
     }

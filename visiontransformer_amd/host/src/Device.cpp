@@ -49,6 +49,13 @@ void hip_check(int e, const char *what) {
 void init(int device) {
   State &s = S();
   if (s.initialised && s.device == device) return;
+  // Blocks, the workspace and the free lists belong to the device they were allocated on: moving
+  // on while any exist would hand pointers of one device to kernels launched on another.
+  if (s.initialised && (s.in_use > 0 || s.cached > 0 || s.ws != nullptr))
+    throw std::runtime_error("vit::init: device " + std::to_string(s.device) + " already holds " +
+                             std::to_string(s.in_use + s.cached + s.ws_bytes) + " bytes of this process's tensors; "
+                             "select device " + std::to_string(device) + " (or join the communicator) before "
+                             "the first tensor is created");
   check(vitk_init(device), "vitk_init");
   s.device = device;
   s.initialised = true;
@@ -185,6 +192,18 @@ void set_dropout_state(uint64_t seed, uint64_t offset) {
   S().dropout_seed = seed - S().dropout_salt;
   S().dropout_offset = offset;
 }
+
+void get_dropout_base_state(uint64_t *seed_out, uint64_t *offset_out) {
+  *seed_out = S().dropout_seed;
+  *offset_out = S().dropout_offset;
+}
+
+void set_dropout_base_state(uint64_t seed, uint64_t offset) {
+  S().dropout_seed = seed;
+  S().dropout_offset = offset;
+}
+
+int current_device() { return S().initialised ? S().device : -1; }
 
 void set_dropout_rank(int rank) { S().dropout_salt = 0xD1B54A32D192ED03ULL * (uint64_t)rank; }
 

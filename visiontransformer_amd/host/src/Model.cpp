@@ -250,10 +250,7 @@ Tensor VisionTransformer::backward(const Tensor &outputGradient) {
   backwardBegin(outputGradient);
   const bool staged_default = wantInputGradient;
   wantInputGradient = true;  // Layer::backward returns the input gradient, as in the reference
-  for (size_t s = 0; s < numBackwardStages(); ++s) {
-    if (s + 1 == numBackwardStages() && discardInputGradient) wantInputGradient = false;
-    backwardStage(s);
-  }
+  for (size_t s = 0; s < numBackwardStages(); ++s) backwardStage(s);
   wantInputGradient = staged_default;
   Tensor out = stageGrad;
   stageGrad = Tensor();

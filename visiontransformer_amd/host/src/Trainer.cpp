@@ -33,7 +33,6 @@ Trainer::Trainer(VisionTransformer &model, const TrainerConfig &train_config, co
     do config.augment_seed = static_cast<uint32_t>(vit::next_seed());
     while (config.augment_seed == 0);
   }
-  model.setDiscardInputGradient(true);  // trainStep drops what model.backward returns (src/model/Trainer.cpp:212)
   if (vit::comm_active()) {
     reducer = std::make_unique<vit::GradientReducer>(model, config.bucket_bytes);
     // replicas start from rank 0's parameters (each process initialised its own)
@@ -54,7 +53,10 @@ float Trainer::trainStep(const Tensor &X_batch, const Tensor &y_batch, float lr_
   const float batch_loss = loss_fn.calculate(logits, y_batch);
   if (accuracy) *accuracy = loss_fn.lastCorrect() / static_cast<float>(X_batch.getShape()[0]);
   Tensor grad = loss_fn.backward(logits, y_batch);
-  model.backward(grad);
+  // The reference drops what model.backward returns (src/model/Trainer.cpp:212): the staged form
+  // does not form the image gradient at all, and leaves the model's own backward() untouched.
+  model.backwardBegin(grad);
+  for (size_t s = 0; s < model.numBackwardStages(); ++s) model.backwardStage(s);
   auto params = model.getParameters();
   auto grads = model.getGradients();
   optimizer.setLearningRate(lr_now);
@@ -113,6 +115,8 @@ void Trainer::train(const std::pair<Tensor, Tensor> &train_data, const std::pair
   for (int epoch = config.start_epoch; epoch < last_epoch; ++epoch) {
     const auto start = std::chrono::high_resolution_clock::now();
     auto [train_loss, train_acc] = train_epoch(X_train, y_train, epoch);
+    vit::synchronize();
+    train_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - start).count());
     if (!quiet) std::cout << "\r" << std::string(80, ' ') << "\r";
     auto [test_loss, test_acc] = evaluate(X_test, y_test);
     const auto ms_total =
@@ -145,8 +149,9 @@ void Trainer::saveState(const std::string &path, int epochs_done) {
   std::ofstream out(path, std::ios::binary);
   if (!out) throw std::runtime_error("No se pudo abrir el archivo de estado para escritura: " + path);
   const int64_t gs = global_step, ts = total_steps, ep = epochs_done;
+  // the unsalted seed: under data parallelism every rank that loads it re-applies its own salt
   uint64_t dseed = 0, doff = 0;
-  vit::get_dropout_state(&dseed, &doff);
+  vit::get_dropout_base_state(&dseed, &doff);
   out.write("VITTRAIN1", 9);
   out.write(reinterpret_cast<const char *>(&gs), sizeof gs);
   out.write(reinterpret_cast<const char *>(&ts), sizeof ts);
@@ -175,7 +180,7 @@ int Trainer::loadState(const std::string &path) {
     throw std::runtime_error("Archivo de estado con formato desconocido: " + path);
   global_step = gs;
   total_steps = ts;
-  vit::set_dropout_state(dseed, doff);
+  vit::set_dropout_base_state(dseed, doff);
   optimizer.readState(in, model.getParameters());
   return (int)ep;
 }

@@ -75,6 +75,8 @@ struct TrainerState {
   }
 };
 
+std::vector<double> g_fit_epoch_ms;  // Trainer::epochTrainMs() of the last vith_fit* call
+
 struct LayerBox {
   std::unique_ptr<Layer> layer;
 };
@@ -124,6 +126,18 @@ int vith_comm_init_file(int rank, int world, const char *path, int timeout_s) {
 int vith_comm_init_external(int rank, int world, vith_allreduce_fn allreduce, vith_broadcast_fn broadcast, void *user,
                             int stream_ordered) {
   return guard([&] { vit::comm_init_external(rank, world, allreduce, broadcast, user, stream_ordered != 0); });
+}
+int vith_comm_exchange_id_file(int rank, int world, const char *path, int timeout_s, void *id128) {
+  return guard([&] {
+    if (!path || !id128) throw std::invalid_argument("vith_comm_exchange_id_file: null pointer");
+    vit::comm_exchange_id_file(rank, world, path, timeout_s > 0 ? timeout_s : 120, id128);
+  });
+}
+int vith_comm_timing(int on) { return guard([&] { vit::comm_timing(on != 0); }); }
+int64_t vith_comm_exposed_ms(double *total_ms) {
+  int64_t n = -1;
+  guard([&] { n = (int64_t)vit::comm_exposed_ms(total_ms); });
+  return n;
 }
 int vith_comm_destroy(void) { return guard([&] { vit::comm_destroy(); }); }
 int vith_comm_rank(void) { return vit::comm_rank(); }
@@ -289,6 +303,9 @@ int vith_backward_image(vith_model m, const float *dlogits_dev, uint64_t B, floa
     if (!dimage_dev) throw std::invalid_argument("vith_backward_image: null output");
     Tensor g = Tensor::wrapDevice(const_cast<float *>(dlogits_dev), {(size_t)B, v.getConfig().num_classes});
     Tensor dimg = v.backward(g);
+    if (!dimg.defined() || dimg.getSize() != (size_t)B * v.getConfig().in_channels * v.getConfig().image_size *
+                                                 v.getConfig().image_size)
+      throw std::runtime_error("vith_backward_image: the model's backward returned no image gradient");
     copy_out(dimg, dimage_dev);
   });
 }
@@ -406,6 +423,7 @@ int vith_fit_augmented(vith_model m, const float *x, const float *y, uint64_t n,
     Trainer trainer(v, tc);
     trainer.setQuiet(true);
     trainer.train(wrap(x, y, n), wrap(x_test, y_test, n_test));
+    g_fit_epoch_ms = trainer.epochTrainMs();
     const auto &h = trainer.history();
     for (size_t e = 0; e < h.size() && history; ++e)
       for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
@@ -432,6 +450,7 @@ int vith_fit_reference_defaults(vith_model m, const float *x, const float *y, ui
     Trainer trainer(v, tc);
     trainer.setQuiet(true);
     trainer.train(wrap(x, y, n), wrap(x_test, y_test, n_test));
+    g_fit_epoch_ms = trainer.epochTrainMs();
     const auto &h = trainer.history();
     for (size_t e = 0; e < h.size() && history; ++e)
       for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
@@ -471,19 +490,24 @@ int vith_fit_with_options(vith_model m, const float *x, const float *y, uint64_t
     trainer.setQuiet(true);
     if (opt->resume) trainer.setStartEpoch(trainer.loadState(tc.state_path));
     trainer.train(wrap(x, y, n), wrap(x_test, y_test, n_test));
+    g_fit_epoch_ms = trainer.epochTrainMs();
     const auto &h = trainer.history();
     for (size_t e = 0; e < h.size() && history; ++e)
       for (int k = 0; k < 4; ++k) history[4 * e + k] = h[e][k];
   });
 }
 uint64_t vith_next_seed(void) { return vit::next_seed(); }
+uint64_t vith_last_fit_epoch_ms(double *ms, uint64_t capacity) {
+  for (size_t e = 0; e < g_fit_epoch_ms.size() && e < capacity && ms; ++e) ms[e] = g_fit_epoch_ms[e];
+  return g_fit_epoch_ms.size();
+}
 int vith_trainer_save_state(vith_trainer t, const char *path) {
   return guard([&] {
     if (!path) throw std::invalid_argument("vith_trainer_save_state: null path");
     std::ofstream out(path, std::ios::binary);
     if (!out) throw std::runtime_error(std::string("No se pudo abrir el archivo de estado para escritura: ") + path);
     uint64_t dseed = 0, doff = 0;
-    vit::get_dropout_state(&dseed, &doff);
+    vit::get_dropout_base_state(&dseed, &doff);
     out.write("VITSTEP1", 8);
     out.write(reinterpret_cast<const char *>(&dseed), sizeof dseed);
     out.write(reinterpret_cast<const char *>(&doff), sizeof doff);
@@ -502,7 +526,7 @@ int vith_trainer_load_state(vith_trainer t, const char *path) {
     in.read(reinterpret_cast<char *>(&doff), sizeof doff);
     if (!in || std::string(magic, 8) != "VITSTEP1")
       throw std::runtime_error(std::string("Archivo de estado con formato desconocido: ") + path);
-    vit::set_dropout_state(dseed, doff);
+    vit::set_dropout_base_state(dseed, doff);
     T(t)->adam.readState(in, T(t)->model->vit.getParameters());
   });
 }
