@@ -108,13 +108,11 @@ void activate(int rank, int world) {
   if (rank < 0 || world < 1 || rank >= world) throw std::invalid_argument("comm_init: rank/world out of range");
   s.rank = rank;
   s.world = world;
-  if (s.stream_ordered && !s.side) {
-    // highest priority the device offers: a collective's few workgroups should be scheduled ahead
-    // of the next backward kernel's thousands instead of queueing behind them
-    int least = 0, greatest = 0;
-    hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    hip_check(hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, greatest), "hipStreamCreate(side stream)");
-  }
+  // (A high-priority side stream was tried and dropped: with hipStreamCreateWithPriority at the
+  // device's greatest priority the event chain compute -> side -> compute of a one-rank run never
+  // completed on ROCm 7.0 -- the step after the first all-reduce hung.)
+  if (s.stream_ordered && !s.side)
+    hip_check(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking), "hipStreamCreate(side stream)");
   // every rank draws different dropout masks for its different samples
   set_dropout_rank(rank);
   s.active = true;
