@@ -603,6 +603,49 @@ def test_gemm_every_slab_count_through_prologue_unrolled_loop_and_tail(K, ta, tb
             K.gemm(dev(a), dev(b), c, M, N, Kd, trans_a=bool(ta), trans_b=bool(tb))
             close(host(c), ref_gemm(a, b, ta, tb), 1e-5)
 
+@pytest.mark.parametrize("tile", ["128x64", "64x128"])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_rectangular_tiles(K, tile, ta, tb):
+    """The 128 x 64 and 64 x 128 output tiles (unguarded kernels), forced: ragged last tile row, short
+    and long contractions, every epilogue operand, and -- for weight gradients -- split-K with the
+    fused column sums and a ragged contraction."""
+    for M, N, Kd in [(5 * 128 + 36, 384, 16 * 25), (256, 128, 16 * 3), (192, 768, 16 * 9)]:
+        a = V.rng_normal(41, *((Kd, M) if ta else (M, Kd)))
+        b, bias, res = V.rng_normal(42, *((N, Kd) if tb else (Kd, N))), V.rng_normal(43, N), V.rng_normal(44, M, N)
+        c, aux = empty(M, N), empty(M, N)
+        K.gemm_profile(True)
+        K.gemm(dev(a), dev(b), c, M, N, Kd, trans_a=bool(ta), trans_b=bool(tb), bias=dev(bias), act=K.ACT_GELU_FWD,
+               aux=aux, residual=dev(res), tile=tile)
+        K.gemm_profile(False)
+        names = [r["name"] for r in K.gemm_profile_read()]
+        assert names == [f"gemm_kernel<{tile.replace('x', ', ')}, {'true' if ta else 'false'}, {'true' if tb else 'false'}, true, false>"], names
+        pre = ref_gemm(a, b, ta, tb) + bias
+        close(host(aux), pre, 1e-5)
+        gelu = 0.5 * pre * (1.0 + np.tanh(0.7978845608028654 * (pre + 0.044715 * pre ** 3)))
+        close(host(c), gelu + res, 1e-5)
+    if ta and not tb:
+        for M, N, Kd, split in [(192, 768, 4096 + 37, 0), (384, 128, 16 * 40 + 1, 3), (128, 64, 300, 1)]:
+            x, dy = V.rng_normal(45, Kd, M), V.rng_normal(46, Kd, N)
+            dw, db = empty(M, N), torch.full((N,), np.nan, device="cuda")
+            K.gemm(dev(x), dev(dy), dw, M, N, Kd, trans_a=True, split_k=split, colsum_b=db, tile=tile)
+            close(host(dw), ref_gemm(x, dy, 1, 0), 1e-5)
+            close(host(db), dy.astype(np.float64).sum(0), 1e-5)
+
+
+def test_gemm_plan_takes_the_rectangular_tile_for_short_contractions_into_wide_outputs(K):
+    """ViT-S's K = 384 into N = 1152: the plan launches 64 x 128 tiles; same product as the square ones."""
+    M, N, Kd = 4096 + 197, 1152, 384
+    a, b = V.rng_normal(47, M, Kd), V.rng_normal(48, Kd, N)
+    c, c64 = empty(M, N), empty(M, N)
+    K.gemm_profile(True)
+    K.gemm(dev(a), dev(b), c, M, N, Kd)
+    K.gemm_profile(False)
+    assert [r["name"] for r in K.gemm_profile_read()] == ["gemm_kernel<64, 128, false, false, true, false>"]
+    close(host(c), ref_gemm(a, b, 0, 0), 1e-5)
+    K.gemm(dev(a), dev(b), c64, M, N, Kd, tile="64x64")
+    np.testing.assert_array_equal(host(c), host(c64))  # the k order of a product does not depend on the tile
+
+
 @pytest.mark.parametrize("B,N,D", [(5, 7, 12), (3, 197, 64), (4, 5, 10)])
 def test_dropout_rows_takes_the_factors_of_the_dense_call(K, B, N, D):
     """vitk_dropout_rows on the first token of every sequence = those rows of vitk_dropout_residual_fwd

@@ -247,12 +247,12 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 // bounds checks at all (a ragged last tile row, and a ragged contraction of a weight-gradient
 // product, are cut off by the extents of the buffer descriptors), the epilogue only a row mask.
 // CS: also form the column sums of B (only with an untransposed B).
-template <int TILE, bool TA, bool TB, bool FULL, bool CS>
+template <int TM, int TN, bool TA, bool TB, bool FULL, bool CS>
 __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Params p) {
   static_assert(!(CS && TB), "column sums need an untransposed B");
-  using OpA = Operand<!TA, TILE>;  // A is k-contiguous when not transposed
-  using OpB = Operand<TB, TILE>;   // B is k-contiguous when transposed
-  constexpr int WT = TILE / 2;     // per-wave tile
+  using OpA = Operand<!TA, TM>;  // A is k-contiguous when not transposed
+  using OpB = Operand<TB, TN>;   // B is k-contiguous when transposed
+  constexpr int WTM = TM / 2, WTN = TN / 2;  // per-wave tile
   constexpr int SA = BK * OpA::LD, SB = BK * OpB::LD;
   __shared__ __attribute__((aligned(16))) float As[STAGES * SA];
   __shared__ __attribute__((aligned(16))) float Bs[STAGES * SB];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   const int strip_items = p.tiles_m * p.strip, sidx = tix / strip_items, rem = tix % strip_items;
   const int strip_w = min(p.strip, p.tiles_n - sidx * p.strip);
   const int tm = rem / strip_w, tn = sidx * p.strip + rem % strip_w;
-  const int m0 = tm * TILE, n0 = tn * TILE;
+  const int m0 = tm * TM, n0 = tn * TN;
 
   const int batch = z / p.split_k, ks = z % p.split_k;
   const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
@@ -292,16 +292,16 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   // under load); the guarded path keeps 32x32x2, whose plain accumulator layout stores whole
   // 128-byte row segments at any alignment.
   constexpr int TW = FULL ? 16 : 32;            // MFMA tile edge
-  constexpr int NTX = WT / TW;                  // MFMA tiles per wave per dimension
+  constexpr int NTM = WTM / TW, NTN = WTN / TW; // MFMA tiles per wave and dimension
   constexpr int KSTEP = FULL ? 4 : 2;           // k per MFMA step
   constexpr int STEPS = BK / KSTEP;             // MFMA steps per slab
   constexpr int KROW = FULL ? 1 : 2;            // LDS k-rows between the operand reads of successive steps
   using AccT = std::conditional_t<FULL, f32x4, f32x16>;
-  AccT acc[NTX][NTX];
+  AccT acc[NTM][NTN];
 #pragma unroll
-  for (int i = 0; i < NTX; ++i)
+  for (int i = 0; i < NTM; ++i)
 #pragma unroll
-    for (int j = 0; j < NTX; ++j)
+    for (int j = 0; j < NTN; ++j)
 #pragma unroll
       for (int r = 0; r < (FULL ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
@@ -350,17 +350,17 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   // operands agree, and k = step + 4*(g&1) + 8*(g>>1) puts the two 16-lane groups that share an
   // LDS cycle 4 k-rows = 16 banks apart (both pitches are 4 mod 32), i.e. conflict-free.
   const int l16 = lane & 15, g16 = lane >> 4, kofs = 4 * (g16 & 1) + 8 * (g16 >> 1);
-  const int lane_a = FULL ? wr * WT + l16 + kofs * OpA::LD : wr * WT + li + lh * OpA::LD;
-  const int lane_b = FULL ? wc * WT + l16 + kofs * OpB::LD : wc * WT + li + lh * OpB::LD;
+  const int lane_a = FULL ? wr * WTM + l16 + kofs * OpA::LD : wr * WTM + li + lh * OpA::LD;
+  const int lane_b = FULL ? wc * WTN + l16 + kofs * OpB::LD : wc * WTN + li + lh * OpB::LD;
   int cur = 0;  // ring slot of slab t
   int t = 0;
   // Operand reads run one k-step ahead of the MFMAs that consume them (two register sets).
-  float a[2][NTX], b[2][NTX];
+  float a[2][NTM], b[2][NTN];
 #define VITK_FIRST_OPERANDS()                                                             \
   lds_barrier();                                                                          \
   VITK_STAMP(1)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < NTX; ++i) a[0][i] = As[lane_a + i * TW];          \
-  _Pragma("unroll") for (int j = 0; j < NTX; ++j) b[0][j] = Bs[lane_b + j * TW];
+  _Pragma("unroll") for (int i = 0; i < NTM; ++i) a[0][i] = As[lane_a + i * TW];          \
+  _Pragma("unroll") for (int j = 0; j < NTN; ++j) b[0][j] = Bs[lane_b + j * TW];
 
   // One slab (index T, prefetch registers RA/RB hold slab T+2 on entry, slab T+4 on exit;
   // STEADY: slabs T+2 and T+4 are known to exist).
@@ -378,18 +378,18 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     _Pragma("unroll") for (int ks = 0; ks < STEPS; ++ks) {                                                  \
       const int c = ks & 1, n = c ^ 1;                                                                      \
       if (ks + 1 < STEPS) {                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < NTX; ++i) a[n][i] = as[KROW * (ks + 1) * OpA::LD + i * TW];   \
-        _Pragma("unroll") for (int j = 0; j < NTX; ++j) b[n][j] = bs[KROW * (ks + 1) * OpB::LD + j * TW];   \
+        _Pragma("unroll") for (int i = 0; i < NTM; ++i) a[n][i] = as[KROW * (ks + 1) * OpA::LD + i * TW];   \
+        _Pragma("unroll") for (int j = 0; j < NTN; ++j) b[n][j] = bs[KROW * (ks + 1) * OpB::LD + j * TW];   \
       } else { /* first k-step of the next slab (after the last slab: a harmless stale read) */             \
-        _Pragma("unroll") for (int i = 0; i < NTX; ++i) a[n][i] = as_n[i * TW];                             \
-        _Pragma("unroll") for (int j = 0; j < NTX; ++j) b[n][j] = bs_n[j * TW];                             \
+        _Pragma("unroll") for (int i = 0; i < NTM; ++i) a[n][i] = as_n[i * TW];                             \
+        _Pragma("unroll") for (int j = 0; j < NTN; ++j) b[n][j] = bs_n[j * TW];                             \
       }                                                                                                     \
-      _Pragma("unroll") for (int i = 0; i < NTX; ++i) _Pragma("unroll") for (int j = 0; j < NTX; ++j) {     \
+      _Pragma("unroll") for (int i = 0; i < NTM; ++i) _Pragma("unroll") for (int j = 0; j < NTN; ++j) {     \
         if constexpr (FULL) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][j], a[c][i], acc[i][j], 0, 0, 0); \
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);        \
       }                                                                                                     \
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NTX, 0);   /* the next step's LDS reads ... */        \
-      __builtin_amdgcn_sched_group_barrier(0x008, NTX * NTX, 0); /* ... then this step's MFMAs */           \
+      __builtin_amdgcn_sched_group_barrier(0x100, NTM + NTN, 0); /* the next step's LDS reads ... */        \
+      __builtin_amdgcn_sched_group_barrier(0x008, NTM * NTN, 0); /* ... then this step's MFMAs */           \
       if (ks == STEPS / 2 - 1) {                                                                               \
         lds_barrier();                                                                                      \
         if (STEADY || (T) + 2 < nslab) {                                                                    \
@@ -490,23 +490,24 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
 
   if constexpr (CS) {
     if (do_colsum) {  // workgroup-uniform
-      // Thread t summed rows t / (TILE/4) (+ multiples) of columns 4*(t % (TILE/4)) .. +3: add the
-      // THREADS / (TILE/4) row groups in a fixed order through LDS (the ring is free by now).
-      constexpr int QUADS = TILE / 4, GROUPS = THREADS / QUADS;
+      // Thread t summed rows t / (TN/4) (+ multiples) of columns 4*(t % (TN/4)) .. +3: add the
+      // THREADS / (TN/4) row groups in a fixed order through LDS (the ring is free by now).
+      constexpr int QUADS = TN / 4, GROUPS = THREADS / QUADS;
+      static_assert(GROUPS * TN <= STAGES * SA, "the column-sum staging must fit the A ring");
       __syncthreads();
-      *reinterpret_cast<f32x4 *>(As + (threadIdx.x / QUADS) * TILE + 4 * (threadIdx.x % QUADS)) = csum;
+      *reinterpret_cast<f32x4 *>(As + (threadIdx.x / QUADS) * TN + 4 * (threadIdx.x % QUADS)) = csum;
       __syncthreads();
-      if (threadIdx.x < TILE && n0 + (int)threadIdx.x < p.N) {
+      if (threadIdx.x < TN && n0 + (int)threadIdx.x < p.N) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g) t += As[g * TILE + threadIdx.x];
+        for (int g = 0; g < GROUPS; ++g) t += As[g * TN + threadIdx.x];
         if (p.split_k > 1) p.colsum_ws[(long long)z * p.N + n0 + threadIdx.x] = t;
         else p.colsum[n0 + threadIdx.x] = t;
       }
     }
   }
 
-  const int row_w = m0 + wr * WT, col_w = n0 + wc * WT;  // this wave's sub-tile origin
+  const int row_w = m0 + wr * WTM, col_w = n0 + wc * WTN;  // this wave's sub-tile origin
   // Epilogue.  Addresses are a uniform base plus one per-lane byte offset per pitch, so the
   // stores (and the residual / pre-activation loads) cost no vector registers for addressing.
   if constexpr (FULL) {
@@ -516,10 +517,10 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
       const unsigned lane_w = (unsigned)((l16 * (long long)p.N + 4 * g16) * 4);
 #pragma unroll
-      for (int i = 0; i < NTX; ++i) {
+      for (int i = 0; i < NTM; ++i) {
         if (row_w + i * 16 + l16 >= p.M) continue;  // ragged last tile row
 #pragma unroll
-        for (int j = 0; j < NTX; ++j)
+        for (int j = 0; j < NTN; ++j)
           *reinterpret_cast<f32x4 *>(W + ((long long)(i * 16) * p.N + j * 16) * 4 + lane_w) = acc[i][j];
       }
     } else {
@@ -531,10 +532,10 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       const unsigned lane_r = (unsigned)((l16 * p.ldr + 4 * g16) * 4);
       const unsigned lane_x = (unsigned)((l16 * p.ldaux + 4 * g16) * 4);
 #pragma unroll
-      for (int i = 0; i < NTX; ++i) {
+      for (int i = 0; i < NTM; ++i) {
         const bool row_ok = row_w + i * 16 + l16 < p.M;  // false only in a ragged last tile row
 #pragma unroll
-        for (int j = 0; j < NTX; ++j) {
+        for (int j = 0; j < NTN; ++j) {
           if (!row_ok) break;
           const int col = col_w + j * 16 + 4 * g16;
           f32x4 *cp = reinterpret_cast<f32x4 *>(C + ((long long)(i * 16) * p.ldc + j * 16) * 4 + lane_c);
@@ -569,9 +570,9 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
       const unsigned lane_w = (unsigned)((4 * lh * (long long)p.N + li) * 4);
 #pragma unroll
-      for (int i = 0; i < NTX; ++i)
+      for (int i = 0; i < NTM; ++i)
 #pragma unroll
-        for (int j = 0; j < NTX; ++j) {
+        for (int j = 0; j < NTN; ++j) {
           const int col = col_w + j * 32 + li;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -590,9 +591,9 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
       const unsigned lane_r = (unsigned)((4 * lh * p.ldr + li) * 4);
       const unsigned lane_x = (unsigned)((4 * lh * p.ldaux + li) * 4);
 #pragma unroll
-      for (int i = 0; i < NTX; ++i)
+      for (int i = 0; i < NTM; ++i)
 #pragma unroll
-        for (int j = 0; j < NTX; ++j) {
+        for (int j = 0; j < NTN; ++j) {
           const int col = col_w + j * 32 + li;
           const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
@@ -678,7 +679,9 @@ unsigned long long *g_stamps = nullptr;
 #endif
 
 struct Plan {
-  int tile, tiles_m, tiles_n, batch, split_k, k_chunk;
+  int tile;  // square tile edge the heuristics below reason with: 128 or 64
+  int tile_m, tile_n;  // the launched tile (tile x tile, or 128 x 64 / 64 x 128)
+  int tiles_m, tiles_n, batch, split_k, k_chunk;
 };
 
 int choose_split(long long tiles, int K) {
@@ -713,6 +716,29 @@ int choose_split(long long tiles, int K) {
   return best_s;
 }
 
+// Rectangular tiles (unguarded kernels only: whole tiles along N, 16-byte-aligned operands -- the
+// caller falls back to the square tile when the launch turns out not to qualify).
+//   reserved == 2 / 3: 128 x 64 / 64 x 128 forced (measurement, tests).
+void choose_rectangular(const vitk_gemm_args *a, Plan *pl) {
+  int tm = pl->tile_m, tn = pl->tile_n;
+  if (a->reserved == 2) tm = 128, tn = 64;
+  else if (a->reserved == 3) tm = 64, tn = 128;
+  else if (a->reserved != 0) return;
+  // Short contractions into wide outputs (ViT-S: K = 384 into N = 1152 / 1536): 64 x 128 tiles run
+  // 3-5 % ahead of both square tiles (twice the workgroups of the 128 x 128 tile to overlap the
+  // fill and store phases that a 24-slab contraction leaves exposed, three quarters of the 64 x 64
+  // tile's operand reads); no gain from K = 768 on, and none at K = 192 either shape.
+  else if (!a->trans_a && a->K > 256 && a->K <= 512 && a->N % 128 == 0 && a->N >= 1024 && a->M >= 4096 && pl->split_k == 1 &&
+           pl->batch == 1)
+    tm = 64, tn = 128;
+  if (tm == pl->tile_m && tn == pl->tile_n) return;
+  if (a->N % tn != 0) return;
+  pl->tile_m = tm;
+  pl->tile_n = tn;
+  pl->tiles_m = (a->M + tm - 1) / tm;
+  pl->tiles_n = a->N / tn;
+}
+
 int make_plan(const vitk_gemm_args *a, Plan *pl) {
   const int bo = a->batch_outer > 0 ? a->batch_outer : 1, bi = a->batch_inner > 0 ? a->batch_inner : 1;
   pl->batch = bo * bi;
@@ -724,7 +750,10 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
   const bool can_split = plain0 && a->split_k != 1 && a->K >= 4096;
   // N a multiple of 64 but not of 128 (D = 192, 3D = 576): 64-wide tiles keep the unguarded path
   const bool n_wants_64 = a->N % 128 != 0 && a->N % 64 == 0;
-  pl->tile = (a->reserved != 1 && !n_wants_64 && a->M >= 128 && a->N >= 128 && (t128 >= 64 || can_split)) ? 128 : 64;
+  // the same for a short M (weight gradients of D = 192: 1.5 tiles of 128 rows waste a quarter of
+  // the launch; 192 x 768 over 50 432 rows: 92 vs 120 TFLOP/s)
+  const bool m_wants_64 = a->M % 128 != 0 && a->M % 64 == 0 && a->M < 1024;
+  pl->tile = (a->reserved != 1 && !n_wants_64 && !m_wants_64 && a->M >= 128 && a->N >= 128 && (t128 >= 64 || can_split)) ? 128 : 64;
   pl->tiles_m = (a->M + pl->tile - 1) / pl->tile;
   pl->tiles_n = (a->N + pl->tile - 1) / pl->tile;
   const bool plain = a->alpha == 1.0f && a->bias == nullptr && a->residual == nullptr && a->act == VITK_ACT_NONE;
@@ -766,24 +795,26 @@ int make_plan(const vitk_gemm_args *a, Plan *pl) {
       pl->tiles_n = (a->N + 63) / 64;
     }
   }
+  pl->tile_m = pl->tile_n = pl->tile;
+  choose_rectangular(a, pl);
   return 0;
 }
 
-template <int TILE, bool FULL>
+template <int TM, int TN, bool FULL>
 void launch2(const Params &p, bool ta, bool tb, dim3 grid, hipStream_t st) {
   const bool cs = p.colsum != nullptr;
-  if (!ta && !tb && !cs) hipLaunchKernelGGL((gemm_kernel<TILE, false, false, FULL, false>), grid, dim3(THREADS), 0, st, p);
-  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, false, FULL, true>), grid, dim3(THREADS), 0, st, p);
-  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<TILE, false, true, FULL, false>), grid, dim3(THREADS), 0, st, p);
-  else if (ta && !tb && !cs) hipLaunchKernelGGL((gemm_kernel<TILE, true, false, FULL, false>), grid, dim3(THREADS), 0, st, p);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<TILE, true, false, FULL, true>), grid, dim3(THREADS), 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<TILE, true, true, FULL, false>), grid, dim3(THREADS), 0, st, p);
+  if (!ta && !tb && !cs) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, FULL, false>), grid, dim3(THREADS), 0, st, p);
+  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, FULL, true>), grid, dim3(THREADS), 0, st, p);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, FULL, false>), grid, dim3(THREADS), 0, st, p);
+  else if (ta && !tb && !cs) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, FULL, false>), grid, dim3(THREADS), 0, st, p);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, FULL, true>), grid, dim3(THREADS), 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true, FULL, false>), grid, dim3(THREADS), 0, st, p);
 }
 
 template <int TILE>
 void launch(const Params &p, bool ta, bool tb, bool full, dim3 grid, hipStream_t st) {
-  if (full) launch2<TILE, true>(p, ta, tb, grid, st);
-  else launch2<TILE, false>(p, ta, tb, grid, st);
+  if (full) launch2<TILE, TILE, true>(p, ta, tb, grid, st);
+  else launch2<TILE, TILE, false>(p, ta, tb, grid, st);
 }
 
 bool strides_vec_ok(const float *p, long long ld, long long so, long long si) {
@@ -813,8 +844,10 @@ hipEvent_t prof_event() {
   return e;
 }
 
-int variant_of(int tile, bool ta, bool tb, bool full, bool cs) {
-  return (cs ? 16 : 0) + (full ? 8 : 0) + (tile == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0);
+constexpr int kVariants = 52;  // 32 square-tile kernels, 4 small-problem kernels, 2 x 8 rectangular ones
+int variant_of(int tile_m, int tile_n, bool ta, bool tb, bool full, bool cs) {
+  if (tile_m != tile_n) return 36 + (tile_m == 128 ? 0 : 8) + (cs ? 4 : 0) + (ta ? 2 : 0) + (tb ? 1 : 0);
+  return (cs ? 16 : 0) + (full ? 8 : 0) + (tile_m == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0);
 }
 
 }  // namespace
@@ -869,7 +902,7 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   // remainder after the last full round (N = 768: 394 x 6 tiles = 3 rounds + 60), those few 128-wide
   // tiles would each run alone on a CU while most CUs idle.  Cut the trailing tile rows off and run
   // them as a second launch, which make_plan covers with four times as many 64-wide tiles.
-  if (a->reserved == 0 && pl.tile == 128 && pl.split_k == 1 && pl.batch == 1 &&
+  if (a->reserved == 0 && pl.tile_m == 128 && pl.tile_n == 128 && pl.split_k == 1 && pl.batch == 1 &&
       a->colsum_b == nullptr) {
     const int slots = vitk::cu_count() * kBlocksPerCU;
     const int tail_max = vitk::cu_count() / 2;  // larger remainders already spread over most CUs (measured: no gain)
@@ -924,10 +957,9 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
 #endif
 
   hipStream_t st = vitk::as_stream(stream);
-  dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)(pl.batch * pl.split_k), 1);
   // every K chunk starts and ends on a slab boundary when K and the chunk are multiples of BK
   // ragged M is masked in the epilogue; a ragged K only where k is the slow index of both operands
-  const bool full = p.vec_a && p.vec_b && a->N % pl.tile == 0 && a->K > 0 &&
+  const bool full = p.vec_a && p.vec_b && a->N % pl.tile_n == 0 && a->K > 0 &&
                     (a->K % BK == 0 || (a->trans_a && !a->trans_b)) && pl.k_chunk % BK == 0 && a->lda < (1 << 21) && a->ldb < (1 << 21) &&
                     (!a->trans_a || (long long)(a->K + BK) * a->lda * 4 < (1ll << 31)) &&
                     (a->trans_b || (long long)(a->K + BK) * a->ldb * 4 < (1ll << 31)) &&
@@ -937,15 +969,28 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
                     (a->aux == nullptr || strides_vec_ok(a->aux, a->ldaux, 0, 0)) &&
                     (a->bias == nullptr || vitk::aligned16(a->bias)) &&
                     (pl.split_k == 1 || vitk::aligned16(a->workspace));
+  if (!full && pl.tile_m != pl.tile_n) {  // the rectangular tiles exist unguarded only
+    pl.tile_m = pl.tile_n = pl.tile;
+    pl.tiles_m = (a->M + pl.tile - 1) / pl.tile;
+    pl.tiles_n = (a->N + pl.tile - 1) / pl.tile;
+    p.tiles_m = pl.tiles_m;
+    p.tiles_n = pl.tiles_n;
+    constexpr int kMaxStrip = 8;
+    const int nstrips = (pl.tiles_n + kMaxStrip - 1) / kMaxStrip;
+    p.strip = (pl.tiles_n + nstrips - 1) / nstrips;
+  }
+  dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)(pl.batch * pl.split_k), 1);
   ProfRec rec{};
   if (g_prof_on) {
-    rec.variant = variant_of(pl.tile, a->trans_a != 0, a->trans_b != 0, full, a->colsum_b != nullptr);
+    rec.variant = variant_of(pl.tile_m, pl.tile_n, a->trans_a != 0, a->trans_b != 0, full, a->colsum_b != nullptr);
     rec.flops = 2.0 * a->M * a->N * a->K * pl.batch;
     rec.e0 = prof_event();
     rec.e1 = prof_event();
     (void)hipEventRecord(rec.e0, st);
   }
-  if (pl.tile == 128) launch<128>(p, a->trans_a != 0, a->trans_b != 0, full, grid, st);
+  if (pl.tile_m == 128 && pl.tile_n == 64) launch2<128, 64, true>(p, a->trans_a != 0, a->trans_b != 0, grid, st);
+  else if (pl.tile_m == 64 && pl.tile_n == 128) launch2<64, 128, true>(p, a->trans_a != 0, a->trans_b != 0, grid, st);
+  else if (pl.tile == 128) launch<128>(p, a->trans_a != 0, a->trans_b != 0, full, grid, st);
   else launch<64>(p, a->trans_a != 0, a->trans_b != 0, full, grid, st);
   if (g_prof_on) {
     (void)hipEventRecord(rec.e1, st);
@@ -978,7 +1023,7 @@ extern "C" int vitk_gemm_profile_enable(int on) {
 
 extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *total_flops, int64_t *launches,
                                       int reset) {
-  VITK_REQUIRE(variant >= 0 && variant < 36, "vitk_gemm_profile_read: variant %d outside [0,36)", variant);
+  VITK_REQUIRE(variant >= 0 && variant < kVariants, "vitk_gemm_profile_read: variant %d outside [0,%d)", variant, kVariants);
   double ms = 0.0, fl = 0.0;
   int64_t n = 0;
   for (const ProfRec &r : g_prof) {
@@ -1006,16 +1051,22 @@ extern "C" int vitk_gemm_profile_read(int variant, double *total_ms, double *tot
 }
 
 extern "C" const char *vitk_gemm_variant_name(int variant) {
-  // the names a profiler prints: gemm_kernel<TILE, TA, TB, FULL, CS>
-  static char names[36][48];
-  if (variant < 0 || variant >= 36) return "";
+  // the names a profiler prints: gemm_kernel<TM, TN, TA, TB, FULL, CS>
+  static char names[kVariants][56];
+  if (variant < 0 || variant >= kVariants) return "";
+  if (variant >= 36) {
+    const int v = variant - 36;
+    std::snprintf(names[variant], sizeof names[variant], "gemm_kernel<%s, %s, %s, true, %s>", v & 8 ? "64, 128" : "128, 64",
+                  v & 2 ? "true" : "false", v & 1 ? "true" : "false", v & 4 ? "true" : "false");
+    return names[variant];
+  }
   if (variant >= 32) {  // gemm_small_kernel<AV, BV>: the template flags depend on alignment; name the transposes
     std::snprintf(names[variant], sizeof names[variant], "gemm_small_kernel (%s)",
                   variant == 32 ? "NN" : variant == 33 ? "NT" : variant == 34 ? "TN" : "TT");
     return names[variant];
   }
   const bool cs = variant & 16, full = variant & 8, t64 = variant & 4, ta = variant & 2, tb = variant & 1;
-  std::snprintf(names[variant], sizeof names[variant], "gemm_kernel<%d, %s, %s, %s, %s>", t64 ? 64 : 128,
+  std::snprintf(names[variant], sizeof names[variant], "gemm_kernel<%d, %d, %s, %s, %s, %s>", t64 ? 64 : 128, t64 ? 64 : 128,
                 ta ? "true" : "false", tb ? "true" : "false", full ? "true" : "false", cs ? "true" : "false");
   return names[variant];
 }

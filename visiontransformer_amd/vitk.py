@@ -149,10 +149,13 @@ def init(device=0):
 
 def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, alpha=1.0,
          act=ACT_NONE, bias=None, residual=None, ldr=None, aux=None, ldaux=None, batch_outer=1, batch_inner=1,
-         stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), split_k=1, workspace=None, st=None, colsum_b=None):
+         stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), split_k=1, workspace=None, st=None, colsum_b=None,
+         tile=None):
     """C = epilogue(alpha * op(A) op(B)); see include/vitk.h.  With split_k != 1 and no workspace given,
-    one is allocated with torch (tests only; the host layer passes its own)."""
+    one is allocated with torch (tests only; the host layer passes its own).  tile: None = the
+    library's choice; "64x64", "128x64", "64x128" force that output tile (tests, measurements)."""
     a = GemmArgs()
+    a.reserved = {None: 0, "64x64": 1, "128x64": 2, "64x128": 3}[tile]
     a.trans_a, a.trans_b, a.M, a.N, a.K = int(trans_a), int(trans_b), M, N, K
     a.A, a.B, a.C = ptr(A), ptr(B), ptr(Cout)
     a.lda = lda if lda is not None else (M if trans_a else K)
@@ -197,7 +200,7 @@ def gemm_profile(enable):
 def gemm_profile_read(reset=True):
     """Per kernel variant: dict(name, ms, flops, launches) for variants that were launched."""
     out = []
-    for v in range(36):
+    for v in range(52):
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         check(dll().vitk_gemm_profile_read(v, C.byref(ms), C.byref(fl), C.byref(n), 0))
         if n.value:
