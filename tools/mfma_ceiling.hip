@@ -16,6 +16,7 @@
 //            its data being what the writes store (the GEMM's slab fetch)
 //   g        f + a workgroup barrier per 64 MFMAs                                        3
 //   h, i     c and g with the operand reads as ds_read_b128 (a quarter of the instructions)
+//   j        g with one operand read as ds_read_b128, the other as four ds_read_b32
 //
 // Per variant: TFLOP/s over the last second of >= 2 s of launches (HIP events), and the clock a
 // workgroup saw inside the last launch (delta s_memtime / delta s_memrealtime x 100 MHz, median
@@ -78,6 +79,17 @@ __device__ __forceinline__ void read_set_wide(uint32_t addr, float (&na)[4], flo
     nb[i] = y[i];
   }
 }
+// One operand wide, the other narrow: one ds_read_b128 + four ds_read_b32 (five instructions).
+template <int U>
+__device__ __forceinline__ void read_set_mixed(uint32_t addr, float (&na)[4], float (&nb)[4]) {
+  f4 x;
+  asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b32 %1, %5 offset:%7\n\tds_read_b32 %2, %5 offset:%8\n\t"
+               "ds_read_b32 %3, %5 offset:%9\n\tds_read_b32 %4, %5 offset:%10"
+               : "=v"(x), "=v"(nb[0]), "=v"(nb[1]), "=v"(nb[2]), "=v"(nb[3])
+               : "v"(addr), "n"((U * 2 + 0) * 1024), "n"((U * 8 + 4) * 256), "n"((U * 8 + 5) * 256), "n"((U * 8 + 6) * 256),
+                 "n"((U * 8 + 7) * 256));
+  for (int i = 0; i < 4; ++i) na[i] = x[i];
+}
 // the reads have landed; tied to the registers so that nothing uses them earlier
 __device__ __forceinline__ void landed(float (&na)[4], float (&nb)[4]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
@@ -95,12 +107,13 @@ __device__ __forceinline__ void write_set(uint32_t addr, float v0, float v1, flo
 }
 
 // MODE 0: MFMAs only; 1: + operand reads; 2: + slab writes; 3: + slab fetch; 4: + barriers
-template <int MODE, int U, bool WIDE>
+template <int MODE, int U, int WIDE>
 __device__ __forceinline__ void one_set(uint32_t addr, uint32_t waddr, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff,
                                         uint32_t soff, f4 &pend, float (&a)[4], float (&b)[4], f4 (&acc)[4][4]) {
   float na[4], nb[4];
-  if (MODE >= 1 && !WIDE) read_set<U>(addr, na, nb);
-  if (MODE >= 1 && WIDE) read_set_wide<U>(addr, na, nb);
+  if (MODE >= 1 && WIDE == 0) read_set<U>(addr, na, nb);
+  if (MODE >= 1 && WIDE == 1) read_set_wide<U>(addr, na, nb);
+  if (MODE >= 1 && WIDE == 2) read_set_mixed<U>(addr, na, nb);
   if (MODE == 2) write_set<U>(waddr, a[0], a[1], b[0], b[1]);
   if (MODE >= 3) {
     write_set<U>(waddr, pend[0], pend[1], pend[2], pend[3]);
@@ -121,7 +134,7 @@ __device__ __forceinline__ void one_set(uint32_t addr, uint32_t waddr, __amdgpu_
   if (MODE >= 4 && (U & 3) == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MODE, bool WIDE>
+template <int MODE, int WIDE>
 __global__ __launch_bounds__(kThreads, 3) void mfma16_kernel(const float *__restrict__ src, float *__restrict__ sink,
                                                              Stamp *__restrict__ stamps, int trips) {
   __shared__ float lds[kLdsFloats + (MODE >= 2 ? kWriteFloats : 0)];
@@ -245,19 +258,21 @@ int main(int argc, char **argv) {
                   {"f e + slab fetch (L2-resident)", 3, 3},
                   {"g f + barrier per 64 MFMAs", 3, 4},
                   {"h c with ds_read_b128 (2 per 16 MFMAs)", 3, 5},
-                  {"i g with ds_read_b128", 3, 6}};
+                  {"i g with ds_read_b128", 3, 6},
+                  {"j g with one ds_read_b128 + four ds_read_b32", 3, 7}};
   for (const Variant &v : variants) {
     const int blocks = cus * v.waves_per_simd;
     const int trips = 3072 / v.waves_per_simd * 3;  // about 16 ms per launch
     auto launch = [&] {
       switch (v.kind) {
-        case 5: hipLaunchKernelGGL((mfma16_kernel<1, true>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
-        case 6: hipLaunchKernelGGL((mfma16_kernel<4, true>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
-        case 0: hipLaunchKernelGGL((mfma16_kernel<0, false>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
-        case 1: hipLaunchKernelGGL((mfma16_kernel<1, false>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
-        case 2: hipLaunchKernelGGL((mfma16_kernel<2, false>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
-        case 3: hipLaunchKernelGGL((mfma16_kernel<3, false>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
-        case 4: hipLaunchKernelGGL((mfma16_kernel<4, false>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 7: hipLaunchKernelGGL((mfma16_kernel<4, 2>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 5: hipLaunchKernelGGL((mfma16_kernel<1, 1>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 6: hipLaunchKernelGGL((mfma16_kernel<4, 1>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 0: hipLaunchKernelGGL((mfma16_kernel<0, 0>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 1: hipLaunchKernelGGL((mfma16_kernel<1, 0>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 2: hipLaunchKernelGGL((mfma16_kernel<2, 0>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 3: hipLaunchKernelGGL((mfma16_kernel<3, 0>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
+        case 4: hipLaunchKernelGGL((mfma16_kernel<4, 0>), dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips); break;
         default: hipLaunchKernelGGL(mfma32_kernel, dim3(blocks), dim3(kThreads), 0, 0, src, sink, stamps, trips);
       }
     };

@@ -30,6 +30,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // native vector (not HIP's f32x4 struct): keeps the staging registers out of scratch memory
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16;
 constexpr int THREADS = 256;
@@ -350,16 +351,30 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   // operands agree, and k = step + 4*(g&1) + 8*(g>>1) puts the two 16-lane groups that share an
   // LDS cycle 4 k-rows = 16 banks apart (both pitches are 4 mod 32), i.e. conflict-free.
   const int l16 = lane & 15, g16 = lane >> 4, kofs = 4 * (g16 & 1) + 8 * (g16 >> 1);
-  const int lane_a = FULL ? wr * WTM + l16 + kofs * OpA::LD : wr * WTM + li + lh * OpA::LD;
+  // FULL: the A-side lane takes NTM CONSECUTIVE rows, one per MFMA tile (tile i of the wave = rows
+  // NTM * l + i), so that its operands of a k-step are one 8- or 16-byte LDS read instead of NTM
+  // 4-byte ones; which rows make up a tile is free, the epilogue follows the same map.
+  const int lane_a = FULL ? wr * WTM + NTM * l16 + kofs * OpA::LD : wr * WTM + li + lh * OpA::LD;
   const int lane_b = FULL ? wc * WTN + l16 + kofs * OpB::LD : wc * WTN + li + lh * OpB::LD;
   int cur = 0;  // ring slot of slab t
   int t = 0;
   // Operand reads run one k-step ahead of the MFMAs that consume them (two register sets).
   float a[2][NTM], b[2][NTN];
+  // the A operands of one k-step at `ptr` (FULL: one vector read; else one tile edge apart)
+#define VITK_READ_A(DST, PTR)                                                                       \
+  if constexpr (FULL && NTM == 4) {                                                                 \
+    const f32x4 v_ = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned((PTR), 16));         \
+    DST[0] = v_.x, DST[1] = v_.y, DST[2] = v_.z, DST[3] = v_.w;                                     \
+  } else if constexpr (FULL && NTM == 2) {                                                          \
+    const f32x2 v_ = *reinterpret_cast<const f32x2 *>(__builtin_assume_aligned((PTR), 8));          \
+    DST[0] = v_.x, DST[1] = v_.y;                                                                   \
+  } else {                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NTM; ++i) DST[i] = (PTR)[i * TW];                         \
+  }
 #define VITK_FIRST_OPERANDS()                                                             \
   lds_barrier();                                                                          \
   VITK_STAMP(1)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < NTM; ++i) a[0][i] = As[lane_a + i * TW];          \
+  VITK_READ_A(a[0], As + lane_a)                                                          \
   _Pragma("unroll") for (int j = 0; j < NTN; ++j) b[0][j] = Bs[lane_b + j * TW];
 
   // One slab (index T, prefetch registers RA/RB hold slab T+2 on entry, slab T+4 on exit;
@@ -378,17 +393,17 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
     _Pragma("unroll") for (int ks = 0; ks < STEPS; ++ks) {                                                  \
       const int c = ks & 1, n = c ^ 1;                                                                      \
       if (ks + 1 < STEPS) {                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < NTM; ++i) a[n][i] = as[KROW * (ks + 1) * OpA::LD + i * TW];   \
+        VITK_READ_A(a[n], as + KROW * (ks + 1) * OpA::LD)                                                   \
         _Pragma("unroll") for (int j = 0; j < NTN; ++j) b[n][j] = bs[KROW * (ks + 1) * OpB::LD + j * TW];   \
       } else { /* first k-step of the next slab (after the last slab: a harmless stale read) */             \
-        _Pragma("unroll") for (int i = 0; i < NTM; ++i) a[n][i] = as_n[i * TW];                             \
+        VITK_READ_A(a[n], as_n)                                                                             \
         _Pragma("unroll") for (int j = 0; j < NTN; ++j) b[n][j] = bs_n[j * TW];                             \
       }                                                                                                     \
       _Pragma("unroll") for (int i = 0; i < NTM; ++i) _Pragma("unroll") for (int j = 0; j < NTN; ++j) {     \
         if constexpr (FULL) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][j], a[c][i], acc[i][j], 0, 0, 0); \
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);        \
       }                                                                                                     \
-      __builtin_amdgcn_sched_group_barrier(0x100, NTM + NTN, 0); /* the next step's LDS reads ... */        \
+      __builtin_amdgcn_sched_group_barrier(0x100, (FULL ? 1 : NTM) + NTN, 0); /* the next step's LDS reads ... */ \
       __builtin_amdgcn_sched_group_barrier(0x008, NTM * NTN, 0); /* ... then this step's MFMAs */           \
       if (ks == STEPS / 2 - 1) {                                                                               \
         lds_barrier();                                                                                      \
@@ -485,6 +500,7 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
 #undef VITK_STAGE_LIT
 #undef VITK_STAGE_SUMS
 #undef VITK_FIRST_OPERANDS
+#undef VITK_READ_A
 #undef VITK_FETCH
   VITK_STAMP(2)
 
@@ -511,36 +527,37 @@ __global__ __launch_bounds__(THREADS, kBlocksPerCU) void gemm_kernel(const Param
   // Epilogue.  Addresses are a uniform base plus one per-lane byte offset per pitch, so the
   // stores (and the residual / pre-activation loads) cost no vector registers for addressing.
   if constexpr (FULL) {
-    // Transposed accumulators: lane l of the 16x16 tile holds C[l&15][4*(l>>4) + 0..3] -- one
-    // 16-byte store per lane and tile, 64 contiguous bytes per row and instruction.
+    // Transposed accumulators: lane l of tile (i, j) holds C[NTM * (l&15) + i][16 j + 4*(l>>4) + 0..3]
+    // (rows interleaved over the tiles, see lane_a) -- one 16-byte store per lane and tile, 64
+    // contiguous bytes per row and instruction.
     if (p.split_k > 1) {
       char *W = reinterpret_cast<char *>(p.ws + (long long)z * p.M * p.N + (long long)row_w * p.N + col_w);
-      const unsigned lane_w = (unsigned)((l16 * (long long)p.N + 4 * g16) * 4);
+      const unsigned lane_w = (unsigned)((NTM * l16 * (long long)p.N + 4 * g16) * 4);
 #pragma unroll
       for (int i = 0; i < NTM; ++i) {
-        if (row_w + i * 16 + l16 >= p.M) continue;  // ragged last tile row
+        if (row_w + NTM * l16 + i >= p.M) continue;  // ragged last tile row
 #pragma unroll
         for (int j = 0; j < NTN; ++j)
-          *reinterpret_cast<f32x4 *>(W + ((long long)(i * 16) * p.N + j * 16) * 4 + lane_w) = acc[i][j];
+          *reinterpret_cast<f32x4 *>(W + ((long long)i * p.N + j * 16) * 4 + lane_w) = acc[i][j];
       }
     } else {
       char *C = reinterpret_cast<char *>(p.C + bo * p.sc_o + bi * p.sc_i + (long long)row_w * p.ldc + col_w);
       const char *R =
           reinterpret_cast<const char *>(p.residual ? p.residual + (long long)row_w * p.ldr + col_w : nullptr);
       char *X = reinterpret_cast<char *>(p.aux ? p.aux + (long long)row_w * p.ldaux + col_w : nullptr);
-      const unsigned lane_c = (unsigned)((l16 * p.ldc + 4 * g16) * 4);
-      const unsigned lane_r = (unsigned)((l16 * p.ldr + 4 * g16) * 4);
-      const unsigned lane_x = (unsigned)((l16 * p.ldaux + 4 * g16) * 4);
+      const unsigned lane_c = (unsigned)((NTM * l16 * p.ldc + 4 * g16) * 4);
+      const unsigned lane_r = (unsigned)((NTM * l16 * p.ldr + 4 * g16) * 4);
+      const unsigned lane_x = (unsigned)((NTM * l16 * p.ldaux + 4 * g16) * 4);
 #pragma unroll
       for (int i = 0; i < NTM; ++i) {
-        const bool row_ok = row_w + i * 16 + l16 < p.M;  // false only in a ragged last tile row
+        const bool row_ok = row_w + NTM * l16 + i < p.M;  // false only in a ragged last tile row
 #pragma unroll
         for (int j = 0; j < NTN; ++j) {
           if (!row_ok) break;
           const int col = col_w + j * 16 + 4 * g16;
-          f32x4 *cp = reinterpret_cast<f32x4 *>(C + ((long long)(i * 16) * p.ldc + j * 16) * 4 + lane_c);
-          f32x4 *xp = reinterpret_cast<f32x4 *>(X + ((long long)(i * 16) * p.ldaux + j * 16) * 4 + lane_x);
-          const f32x4 *rp = reinterpret_cast<const f32x4 *>(R + ((long long)(i * 16) * p.ldr + j * 16) * 4 + lane_r);
+          f32x4 *cp = reinterpret_cast<f32x4 *>(C + ((long long)i * p.ldc + j * 16) * 4 + lane_c);
+          f32x4 *xp = reinterpret_cast<f32x4 *>(X + ((long long)i * p.ldaux + j * 16) * 4 + lane_x);
+          const f32x4 *rp = reinterpret_cast<const f32x4 *>(R + ((long long)i * p.ldr + j * 16) * 4 + lane_r);
           f32x4 bv = {0.f, 0.f, 0.f, 0.f}, xv = bv, rv = bv, v, pre;
           if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(p.bias + col);
           if (p.act == VITK_ACT_GELU_BWD) xv = *xp;
