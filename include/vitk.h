@@ -113,6 +113,14 @@ const char *vitk_gemm_variant_name(int variant);
  * results in wave order.  on = 0 keeps everything on the tiled kernel, on = 2 keeps the small kernel at one wave
  * per tile (tests, measurements); the default is 1.  Process-wide. */
 int vitk_gemm_small_enable(int on);
+/* Several launch plans size themselves by the device's CU count: which problems take the
+ * small-problem kernel, the split count of a long contraction, the tile shape, heads per attention
+ * workgroup.  Split counts and kernel routes change the order in which a sum is formed, so the same
+ * model gives results that differ in the last bits between devices with different CU counts (a
+ * partitioned MI355X, for one).  vitk_set_planning_cu_count(n) makes every plan use n instead of
+ * the device's count (n = 256 repeats a whole MI355X's bits anywhere; any n is correct, only
+ * slower or faster); 0 restores the device's own.  Process-wide. */
+int vitk_set_planning_cu_count(int cus);
 
 /* ---- column sum: out[j] = sum_i x[i][j]  (Tensor::sum(0), src/core/Tensor.cpp:385-430; the
  * bias gradient of Dense::backward, src/layers/Dense.cpp:95, and dpos/dcls of

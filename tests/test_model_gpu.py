@@ -567,6 +567,52 @@ def test_model_vs_oracle_at_baseline_shapes(H, name, B):
         off += k
 
 
+@pytest.mark.parametrize("cus", [32, 64, 1024])
+@pytest.mark.parametrize("name,B", [("C1", 128), ("C2", 64), ("C3", 3)])
+def test_model_vs_oracle_with_the_plans_of_other_device_sizes(H, name, B, cus):
+    """Kernel routes, split counts and tile shapes are sized by the CU count, and they set the order
+    of the sums: a device partition with 32 or 64 CUs (or a larger chip) takes other routes than the
+    256-CU device the golden bounds were established on.  The oracle comparison must hold on every
+    one of them; vitk_set_planning_cu_count selects the plans without needing the device."""
+    from visiontransformer_amd import vitk
+    vitk.planning_cu_count(cus)
+    try:
+        test_model_vs_oracle_at_baseline_shapes(H, name, B)
+    finally:
+        vitk.planning_cu_count(0)
+
+
+def test_planning_cu_count_repeats_a_device_s_bits(H):
+    """Pinned to one CU count, two runs give identical bits; the count is checked."""
+    from visiontransformer_amd import vitk
+    cfgd = V.CONFIGS["C2"]
+    ocfg = V.Cfg.make(**cfgd)
+    prm = V.init_params(ocfg, 3)
+    x = V.rng_normal(4, 64, ocfg.in_channels, ocfg.image_size, ocfg.image_size)
+    y = V.onehot(np.arange(64) % ocfg.num_classes, ocfg.num_classes)
+
+    def grads():
+        m = H.Model(hcfg(H, cfgd))
+        m.set_params(prm)
+        t = H.Trainer(m)
+        t.train_step(dev(x), dev(y), 0.0)
+        return m.get_grads()
+
+    try:
+        vitk.planning_cu_count(64)
+        a = grads()
+        vitk.planning_cu_count(256)
+        b = grads()
+        vitk.planning_cu_count(64)
+        c = grads()
+    finally:
+        vitk.planning_cu_count(0)
+    np.testing.assert_array_equal(a, c)
+    assert V.max_relerr(a, b) <= 1e-4  # other routes, same gradient to rounding
+    with pytest.raises(vitk.VitkError):
+        vitk.planning_cu_count(-1)
+
+
 # ---------------------------------------------------- the benchmark configuration at full size
 VIT_B16 = dict(image_size=224, patch_size=16, in_channels=3, num_classes=1000, embedding_dim=768, num_heads=12,
                num_layers=12, mlp_hidden_dim=3072)

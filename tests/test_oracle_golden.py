@@ -2,6 +2,8 @@
 were produced by the compiled reference (tests/golden/make_golden.py).  Needs neither a GPU nor
 /root/reference.  Tolerance 5e-6 relative to each tensor's scale (the oracle keeps the
 reference's accumulation order; the slack covers libm/OpenMP-order differences only)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -221,3 +223,16 @@ def test_embeddings_image_gradient_golden():
         dimg = V.f32(c["B"], c["C"], c["img"], c["img"])
         O.vo_embeddings_input_grad(c["img"], c["P"], c["C"], c["D"], c["prm"], c["B"], c["dy"], dimg)
         np.testing.assert_array_equal(dimg, g[tag])
+
+
+def test_oracle_runs_clean_under_address_and_undefined_behaviour_sanitizers():
+    """`make -C oracle sanitize`: the C restatement driven through its model-level and layer-level
+    entry points in a -fsanitize=address,undefined build (host code; runtime linked statically)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or shutil.which("make") is None:
+        pytest.skip("needs gcc and make")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "clean" in r.stdout

@@ -23,7 +23,10 @@ int check_launch(const char *what) {
   return 0;
 }
 
+static std::atomic<int> g_planning_cus{0};
+
 int cu_count() {
+  if (const int forced = g_planning_cus.load(std::memory_order_relaxed)) return forced;
   static int cached[64] = {0};  // benign race: every thread writes the same value
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
@@ -51,6 +54,12 @@ extern "C" {
 int vitk_version(void) { return 100; }
 
 const char *vitk_last_error(void) { return vitk::g_err; }
+
+int vitk_set_planning_cu_count(int cus) {
+  VITK_REQUIRE(cus >= 0 && cus <= 4096, "vitk_set_planning_cu_count: %d outside [0, 4096]", cus);
+  vitk::g_planning_cus.store(cus, std::memory_order_relaxed);
+  return 0;
+}
 
 int vitk_init(int device) {
   int count = 0;

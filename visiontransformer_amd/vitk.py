@@ -48,6 +48,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_int64), C.c_int]),
     "vitk_gemm_variant_name": (C.c_char_p, [C.c_int]),
     "vitk_gemm_small_enable": (C.c_int, [C.c_int]),
+    "vitk_set_planning_cu_count": (C.c_int, [C.c_int]),
     "vitk_sdpa_tile16_enable": (C.c_int, [C.c_int]),
     "vitk_sdpa_bwd_tile16_enable": (C.c_int, [C.c_int]),
     "vitk_colsum_workspace_bytes": (_sz, [_i64, _i64]),
@@ -180,6 +181,11 @@ def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=Non
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * 4
     check(dll().vitk_gemm_f32(C.byref(a), st if st is not None else stream()))
     return keep
+
+
+def planning_cu_count(cus):
+    """Plans (kernel routes, split counts, tile shapes) as on a device with `cus` CUs; 0 = this device's."""
+    check(dll().vitk_set_planning_cu_count(int(cus)))
 
 
 def gemm_small(enable):
