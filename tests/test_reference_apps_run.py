@@ -111,6 +111,9 @@ def stage(tmp_path, files):
 def run_app(name, cwd, timeout=110):
     exe = os.path.join(NATIVE, name)
     assert os.path.exists(exe), "built by `make -C tests/native` where the reference tree exists"
+    lib = os.path.join(os.path.dirname(os.path.dirname(NATIVE)), "visiontransformer_amd", "lib", "libvit_host.so")
+    # the applications hold the classes' layouts from the headers they were compiled against
+    assert os.path.getmtime(exe) >= os.path.getmtime(lib), f"{name} is older than libvit_host.so: rebuild with `make -C tests/native`"
     r = subprocess.run([exe], cwd=cwd, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     return r.stdout
