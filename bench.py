@@ -193,11 +193,25 @@ def launch(args, argv):
             status = bad[0][1] if bad[0][1] > 0 else 1
     if status == 0:
         if args.dry_launch:
-            print(json.dumps({"dry_launch": [json.loads(c.stdout.read().decode()) for c in children]}), flush=True)
+            # (libraries may print to the children's stdout as well: each child's report is its last JSON line)
+            reports = [[l for l in c.stdout.read().decode().splitlines() if l.startswith("{")][-1] for c in children]
+            print(json.dumps({"dry_launch": [json.loads(r) for r in reports]}), flush=True)
         else:
             sys.stdout.write(children[0].stdout.read().decode())
             sys.stdout.flush()
     return status
+
+
+def init_group(dist, rank, world):
+    """The CPU (gloo) process group that carries the communicator id, the barriers and the timings.
+    Rendezvous through the launcher's variables (env://): under torch.distributed.run the ranks are
+    clients of the store its agent already serves on MASTER_PORT; started by launch() above, rank 0
+    serves it."""
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29555")
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
 
 def parse_args(argv):
@@ -239,8 +253,17 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_collectives or args.dry_launch):
         sys.exit(launch(args, argv))
     if args.dry_launch:
-        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
-                                                         "MASTER_PORT", "VIT_COMM_RUN_ID")}), flush=True)
+        # what this rank was given, and -- through the same rendezvous the benchmark uses -- who else is there
+        me = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                             "VIT_COMM_RUN_ID")}
+        import torch.distributed as dist
+        init_group(dist, int(me["RANK"]), int(me["WORLD_SIZE"]))
+        seen = [None] * int(me["WORLD_SIZE"])
+        dist.all_gather_object(seen, int(me["RANK"]))
+        dist.barrier()
+        dist.destroy_process_group()
+        me["group_ranks"] = seen
+        os.write(1, (json.dumps(me) + "\n").encode())
         return
     # stdout carries exactly one line, the result: everything libraries print on the way (RCCL's
     # version banner, for one) goes to stderr, and the JSON line is written to the saved descriptor
@@ -268,9 +291,7 @@ def main():
     if collectives:
         # a CPU (gloo) group carries the 128-byte communicator id, the barriers and the timings, so the
         # only RCCL communicator of the process is the host layer's own
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29555")
-        dist.init_process_group("gloo", init_method=f"tcp://{addr}:{port}", rank=rank, world_size=world)
+        init_group(dist, rank, world)
     host.init(local_rank)
     host.use_torch_stream()
     host.set_first_token_tail(not args.dense_tail)

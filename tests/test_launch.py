@@ -33,15 +33,28 @@ def test_bench_starts_its_own_ranks(world):
     assert {k["MASTER_ADDR"] for k in kids} == {"127.0.0.1"}
     assert len({k["MASTER_PORT"] for k in kids}) == 1 and int(kids[0]["MASTER_PORT"]) > 0
     assert len({k["VIT_COMM_RUN_ID"] for k in kids}) == 1 and len(kids[0]["VIT_COMM_RUN_ID"]) == 32
+    # the ranks met in the process group the benchmark uses (gloo over the launcher's variables)
+    assert all(k["group_ranks"] == list(range(world)) for k in kids)
 
 
-def test_bench_under_a_launcher_is_one_rank():
-    """With the launcher's variables present nothing is started: the process reports its own."""
-    r = run_bench("--gpus", "2", "--dry-launch", env={"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2",
-                                                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
-    assert r.returncode == 0, r.stderr
-    me = json.loads(r.stdout)
-    assert me["RANK"] == "1" and me["WORLD_SIZE"] == "2" and me["MASTER_PORT"] == "29999"
+def test_bench_under_torch_distributed_run_is_one_rank_per_process():
+    """The driver's command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.  With the launcher's variables
+    present bench.py starts nothing itself, and its ranks meet through the store the launcher's agent
+    serves on MASTER_PORT (a second server on that port would fail to bind)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--dry-launch"], env=e, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-3000:]
+    kids = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda k: int(k["RANK"]))
+    assert [k["RANK"] for k in kids] == ["0", "1"] and {k["WORLD_SIZE"] for k in kids} == {"2"}
+    assert {k["MASTER_PORT"] for k in kids} == {str(port)}
+    assert all(k["group_ranks"] == [0, 1] for k in kids)
 
 
 def test_a_failing_rank_fails_the_launch():
