@@ -81,7 +81,8 @@ typedef struct vitk_gemm_args {
   int64_t stride_b_outer, stride_b_inner;
   int64_t stride_c_outer, stride_c_inner;
   int32_t split_k; /* 1 = none, 0 = auto */
-  int32_t reserved; /* must be 0 */
+  int32_t reserved; /* 0 = the library's tile plan; 1 / 2 / 3 force 64 x 64 / 128 x 64 / 64 x 128 output tiles
+                     * (measurements and tests; the rectangular ones only where the unguarded kernel applies) */
   float *workspace;
   size_t workspace_bytes;
   /* optional: colsum_b[n] = sum_k B[k][n] (trans_b = 0, batch = 1 only), accumulated from the B
