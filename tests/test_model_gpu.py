@@ -582,6 +582,18 @@ def test_model_vs_oracle_with_the_plans_of_other_device_sizes(H, name, B, cus):
         vitk.planning_cu_count(0)
 
 
+def test_device_cannot_change_once_tensors_exist(H):
+    """Blocks, workspace and cached blocks stay on the device they were allocated on: selecting
+    another device afterwards (a launcher-variable join that comes too late, an explicit init) is
+    refused with a message instead of mixing pointers of two devices."""
+    m = H.Model(hcfg(H, V.TINY))  # holds the parameter arenas on device 0
+    assert H.dll().vith_device_bytes_in_use() > 0
+    with pytest.raises(H.HostError, match="already holds"):
+        H.init(1)
+    H.init(0)  # the same device again is fine
+    del m
+
+
 def test_planning_cu_count_repeats_a_device_s_bits(H):
     """Pinned to one CU count, two runs give identical bits; the count is checked."""
     from visiontransformer_amd import vitk
