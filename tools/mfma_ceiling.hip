@@ -17,6 +17,7 @@
 //   g        f + a workgroup barrier per 64 MFMAs                                        3
 //   h, i     c and g with the operand reads as ds_read_b128 (a quarter of the instructions)
 //   j        g with one operand read as ds_read_b128, the other as four ds_read_b32
+//   k, l     g with two / one workgroup per CU instead of three
 //
 // Per variant: TFLOP/s over the last second of >= 2 s of launches (HIP events), and the clock a
 // workgroup saw inside the last launch (delta s_memtime / delta s_memrealtime x 100 MHz, median
@@ -259,7 +260,9 @@ int main(int argc, char **argv) {
                   {"g f + barrier per 64 MFMAs", 3, 4},
                   {"h c with ds_read_b128 (2 per 16 MFMAs)", 3, 5},
                   {"i g with ds_read_b128", 3, 6},
-                  {"j g with one ds_read_b128 + four ds_read_b32", 3, 7}};
+                  {"j g with one ds_read_b128 + four ds_read_b32", 3, 7},
+                  {"k g at 2 waves/SIMD (a third workgroup in its fill or store phase)", 2, 4},
+                  {"l g at 1 wave/SIMD", 1, 4}};
   for (const Variant &v : variants) {
     const int blocks = cus * v.waves_per_simd;
     const int trips = 3072 / v.waves_per_simd * 3;  // about 16 ms per launch
