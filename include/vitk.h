@@ -94,11 +94,20 @@ typedef struct vitk_gemm_args {
 int vitk_gemm_f32(const vitk_gemm_args *args, vitk_stream_t stream);
 /* Bytes of workspace vitk_gemm_f32 needs for these arguments (0 when it will not split K). */
 size_t vitk_gemm_workspace_bytes(const vitk_gemm_args *args);
+/* The two products of Dense::backward (src/layers/Dense.cpp:90-98) as one call: dx_args describes
+ * dX = dY W^T (trans_a = 0, trans_b = 1; any epilogue), dw_args describes dW = X^T dY (trans_a = 1,
+ * trans_b = 0, optionally colsum_b).  Neither product may read what the other writes.  When both
+ * are problems of the small-problem kernel (below) they run as ONE launch -- on the reference's
+ * own small models a launch costs more than its arithmetic; otherwise this is vitk_gemm_f32 on
+ * dw_args, then on dx_args, each with its own workspace requirement (pass the larger).  Results are
+ * bitwise those of the two separate calls. */
+int vitk_gemm_pair_f32(const vitk_gemm_args *dx_args, const vitk_gemm_args *dw_args, vitk_stream_t stream);
 
 /* Measurement aid for bench.py (not used by the training path): while enabled, every main
  * contraction launch is bracketed by two HIP events on its stream.  variant = 16*colsum + 8*full +
  * 4*(tile==64) + 2*trans_a + trans_b (0..31) identifies the instantiation of the tiled kernel and
- * 32 + 2*trans_a + trans_b the small-problem kernel (vitk_gemm_variant_name gives the name a
+ * 32 + 2*trans_a + trans_b the small-problem kernel, 36 .. 51 the rectangular tiles, 52 the paired
+ * small-problem launch of vitk_gemm_pair_f32 (vitk_gemm_variant_name gives the name a
  * profiler shows); vitk_gemm_profile_read returns the summed event time, the summed algorithmic
  * FLOPs (2*M*N*K*batch) and the launch count of one variant, optionally clearing all records. */
 int vitk_gemm_profile_enable(int on);

@@ -632,6 +632,42 @@ def test_gemm_rectangular_tiles(K, tile, ta, tb):
             close(host(db), dy.astype(np.float64).sum(0), 1e-5)
 
 
+@pytest.mark.parametrize("rows,i,o,gelu", [(640, 96, 384, False), (640, 384, 96, True), (85, 64, 64, False), (320, 96, 288, False),
+                                            (1300, 96, 96, False), (50, 10, 64, False), (9000, 192, 192, False)])
+def test_gemm_pair_of_a_dense_backward_equals_the_two_calls(K, gemm_path, rows, i, o, gelu):
+    """vitk_gemm_pair_f32 (dX = dY W^T with its epilogue, dW = X^T dY with db): bitwise the results
+    of two vitk_gemm_f32 calls, whether it ran as one launch of the small-problem kernel (the first
+    shapes: the 5- and 17-token models' layers) or fell back to two (contractions over more than
+    1024 rows, operands that cannot be read 16 bytes at a time, large outputs)."""
+    x, dy, w = V.rng_normal(51, rows, i), V.rng_normal(52, rows, o), V.rng_normal(53, i, o) * 0.1
+    pre = V.rng_normal(54, rows, i)
+    dx, dw, db = empty(rows, i), empty(i, o), empty(o)
+    dx2, dw2, db2 = empty(rows, i), empty(i, o), empty(o)
+    dX = dict(A=dev(dy), B=dev(w), Cout=dx, M=rows, N=i, K=o, trans_b=True)
+    if gelu:
+        dX.update(act=K.ACT_GELU_BWD, aux=dev(pre))
+    dW = dict(A=dev(x), B=dev(dy), Cout=dw, M=i, N=o, K=rows, trans_a=True, split_k=0, colsum_b=db)
+    K.gemm_profile(True)
+    K.gemm_pair(dX, dW)
+    K.gemm_profile(False)
+    names = [r["name"] for r in K.gemm_profile_read()]
+    K.gemm(**dict(dX, Cout=dx2))
+    K.gemm(**dict(dW, Cout=dw2, colsum_b=db2))
+    np.testing.assert_array_equal(host(dx), host(dx2))
+    np.testing.assert_array_equal(host(dw), host(dw2))
+    np.testing.assert_array_equal(host(db), host(db2))
+    close(host(dw), ref_gemm(x, dy, 1, 0), 1e-5)
+    want_dx = ref_gemm(dy, w, 0, 1)
+    if gelu:
+        O = V.oracle()
+        g = V.f32(rows, i)
+        O.vo_gelu_backward(pre, want_dx.astype(np.float32), rows * i, g)
+        want_dx = g
+    close(host(dx), want_dx, 1e-5)
+    one_launch = rows <= 1024 and o % 4 == 0 and (rows + 15) // 16 * ((i + 15) // 16) <= 8 * 256 and gemm_path != "tiled_only"
+    assert (names == ["gemm_small_pair_kernel (dX NT + dW TN)"]) == one_launch, (names, one_launch)
+
+
 def test_gemm_plan_takes_the_rectangular_tile_for_short_contractions_into_wide_outputs(K):
     """ViT-S's K = 384 into N = 1152: the plan launches 64 x 128 tiles; same product as the square ones."""
     M, N, Kd = 4096 + 197, 1152, 384

@@ -25,6 +25,9 @@ int norm_static_setup();
 // Small-problem GEMM (gemm_small.hip): whether vitk_gemm_f32 routes these arguments to it, and the launch.
 bool gemm_small_applies(const vitk_gemm_args *a);
 int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st);
+// The two products of a Dense backward (dX = dY W^T, dW = X^T dY) as one launch of that kernel.
+bool gemm_small_pair_applies(const vitk_gemm_args *dx, const vitk_gemm_args *dw);
+int gemm_small_pair_launch(const vitk_gemm_args *dx, const vitk_gemm_args *dw, hipStream_t st);
 
 // Forward attention on 16-row tiles (attention16.hip): whether vitk_sdpa_fwd routes a call to it, and the launch.
 bool sdpa_fwd16_applies(int N, int dh, bool vec, float scale, long long ld);

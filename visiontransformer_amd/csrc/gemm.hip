@@ -861,7 +861,7 @@ hipEvent_t prof_event() {
   return e;
 }
 
-constexpr int kVariants = 52;  // 32 square-tile kernels, 4 small-problem kernels, 2 x 8 rectangular ones
+constexpr int kVariants = 53;  // 32 square-tile kernels, 4 small-problem kernels, 2 x 8 rectangular ones, the paired small launch
 int variant_of(int tile_m, int tile_n, bool ta, bool tb, bool full, bool cs) {
   if (tile_m != tile_n) return 36 + (tile_m == 128 ? 0 : 8) + (cs ? 4 : 0) + (ta ? 2 : 0) + (tb ? 1 : 0);
   return (cs ? 16 : 0) + (full ? 8 : 0) + (tile_m == 128 ? 0 : 4) + (ta ? 2 : 0) + (tb ? 1 : 0);
@@ -1028,6 +1028,35 @@ extern "C" int vitk_gemm_f32(const vitk_gemm_args *a, vitk_stream_t stream) {
   return 0;
 }
 
+extern "C" int vitk_gemm_pair_f32(const vitk_gemm_args *x, const vitk_gemm_args *w, vitk_stream_t stream) {
+  VITK_REQUIRE(x != nullptr && w != nullptr, "vitk_gemm_pair_f32: null args");
+  const bool shapes_ok = x->M > 0 && x->N > 0 && x->K > 0 && w->M > 0 && w->N > 0 && w->K > 0 && x->A && x->B && x->C &&
+                         w->A && w->B && w->C && x->lda >= x->K && x->ldb >= x->K && x->ldc >= x->N && w->lda >= w->M &&
+                         w->ldb >= w->N && w->ldc >= w->N && x->act >= VITK_ACT_NONE && x->act <= VITK_ACT_GELU_BWD &&
+                         (x->act != VITK_ACT_GELU_BWD || x->aux != nullptr) && (x->aux == nullptr || x->ldaux >= x->N) &&
+                         (x->residual == nullptr || x->ldr >= x->N) && w->act == VITK_ACT_NONE && w->alpha == 1.0f &&
+                         w->bias == nullptr && w->residual == nullptr;
+  if (shapes_ok && vitk::gemm_small_pair_applies(x, w)) {
+    hipStream_t st = vitk::as_stream(stream);
+    ProfRec rec{};
+    if (g_prof_on) {
+      rec.variant = 52;
+      rec.flops = 2.0 * x->M * x->N * x->K + 2.0 * w->M * w->N * w->K;
+      rec.e0 = prof_event();
+      rec.e1 = prof_event();
+      (void)hipEventRecord(rec.e0, st);
+    }
+    const int rc = vitk::gemm_small_pair_launch(x, w, st);
+    if (g_prof_on) {
+      (void)hipEventRecord(rec.e1, st);
+      g_prof.push_back(rec);
+    }
+    return rc;
+  }
+  if (vitk_gemm_f32(w, stream)) return 1;  // (every argument check lives there)
+  return vitk_gemm_f32(x, stream);
+}
+
 #ifdef VITK_GEMM_STAMPS
 // Diagnostic build only: device buffer of 16 x uint64 per workgroup of the next launches (or null).
 extern "C" void vitk_gemm_set_stamps(unsigned long long *device_buffer) { g_stamps = device_buffer; }
@@ -1071,6 +1100,7 @@ extern "C" const char *vitk_gemm_variant_name(int variant) {
   // the names a profiler prints: gemm_kernel<TM, TN, TA, TB, FULL, CS>
   static char names[kVariants][56];
   if (variant < 0 || variant >= kVariants) return "";
+  if (variant == 52) return "gemm_small_pair_kernel (dX NT + dW TN)";
   if (variant >= 36) {
     const int v = variant - 36;
     std::snprintf(names[variant], sizeof names[variant], "gemm_kernel<%s, %s, %s, true, %s>", v & 8 ? "64, 128" : "128, 64",

@@ -68,13 +68,15 @@ __device__ __forceinline__ f32x4 load4(const float *__restrict__ base, long long
   return v;
 }
 
+// One 16 x 16 output tile (index `tile`, row-major over the tile grid) by the calling workgroup:
+// one wave, or SPLIT waves that share the contraction.
 template <bool AV, bool BV, int SPLIT>
-__global__ __launch_bounds__(64 * SPLIT) void gemm_small_kernel(const SmallParams p) {
+__device__ __forceinline__ void small_tile(const SmallParams &p, const int tile) {
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = SPLIT > 1 ? (int)(threadIdx.x >> 6) : 0;
   const int kb = SPLIT > 1 ? min(wave * p.k_per_wave, p.K) : 0;            // this wave's k: [kb, ke)
   const int ke = SPLIT > 1 ? min(kb + p.k_per_wave, p.K) : p.K;
-  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   // lane (c, g) feeds row m of A and column n of B at k = 16*chunk + 4*g + e into step e of the
   // chunk: v_mfma_f32_16x16x4_f32 takes A[i = lane % 16][k = lane / 16] and B[k = lane / 16][j = lane % 16].
   // Rows and columns beyond the matrix read the last valid one instead: row i of A only reaches
@@ -163,6 +165,32 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_small_kernel(const SmallParam
   }
 }
 
+template <bool AV, bool BV, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void gemm_small_kernel(const SmallParams p) {
+  small_tile<AV, BV, SPLIT>(p, (int)blockIdx.x);
+}
+
+// Two independent products in one launch: the two halves of a Dense layer's backward pass,
+// dX = dY W^T (both operands contiguous along k: one wave per tile) and dW = X^T dY (strided along
+// k; SPLIT waves per tile where the contraction is long).  The first tiles0 workgroups take the
+// first problem -- one tile per WAVE, so that its workgroups are as full as the second problem's,
+// whose SPLIT-wave workgroups take one tile each (a workgroup of eight waves of this kernel fills
+// a CU: with seven of them idle the launch would need two passes over the chip).  On models this
+// small a launch costs more than its arithmetic, so one launch instead of two is the gain.
+struct SmallPair {
+  SmallParams first, second;
+  int tiles0, groups0;  // tiles of the first problem, and the workgroups that take them
+};
+template <int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void gemm_small_pair_kernel(const SmallPair pp) {
+  if ((int)blockIdx.x < pp.groups0) {  // workgroup-uniform
+    const int tile = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    if (tile < pp.tiles0) small_tile<true, true, 1>(pp.first, tile);  // (wave-uniform; no barrier inside)
+  } else {
+    small_tile<false, false, SPLIT>(pp.second, (int)blockIdx.x - pp.groups0);
+  }
+}
+
 bool g_small_on = true;
 bool g_small_split_on = true;
 
@@ -181,7 +209,10 @@ bool gemm_small_applies(const vitk_gemm_args *a) {
   return tiles <= 8LL * cu_count();
 }
 
-int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st) {
+namespace {
+// kernel arguments of one problem; *av / *bv: whether A / B can be read 16 bytes at a time along k;
+// *nw: the number of waves that share a tile's contraction (1 = no split)
+SmallParams small_params(const vitk_gemm_args *a, bool *av, bool *bv, long long *tiles, int *nw_out) {
   SmallParams p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.A = a->A; p.sam = a->trans_a ? 1 : a->lda; p.sak = a->trans_a ? a->lda : 1;
@@ -190,21 +221,59 @@ int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st) {
   p.residual = a->residual; p.ldr = a->ldr; p.aux = a->aux; p.ldaux = a->ldaux;
   p.colsum = a->colsum_b;
   p.tiles_n = (a->N + 15) / 16;
-  const bool av = !a->trans_a && a->lda % 4 == 0 && a->K % 4 == 0 && aligned16(a->A);
-  const bool bv = a->trans_b && a->ldb % 4 == 0 && a->K % 4 == 0 && aligned16(a->B);
-  const long long tiles = (long long)((a->M + 15) / 16) * p.tiles_n;
-  const dim3 grid((unsigned)tiles);
+  *av = !a->trans_a && a->lda % 4 == 0 && a->K % 4 == 0 && aligned16(a->A);
+  *bv = a->trans_b && a->ldb % 4 == 0 && a->K % 4 == 0 && aligned16(a->B);
+  *tiles = (long long)((a->M + 15) / 16) * p.tiles_n;
   // a long contraction over few tiles: four waves per tile, a quarter of k each, while that still
   // leaves (nearly) every wave a SIMD of its own
   // (one batch of loads = 16 * U k per wave: every wave makes a single round trip to memory)
-  const int nw = (a->K + 16 * U - 1) / (16 * U);
   // Only for the weight-gradient form (A^T B: k runs over the token rows, up to 1024 of them
   // here).  Those results go straight into the optimizer; activations and activation gradients
   // keep the single chain in k order, whose rounding stays closest to the reference's sequential
   // sum -- a different association there is amplified by every layer the value still passes
   // through (measured: twelve layers take it to the edge of the 1e-4 parity bound).
-  const bool split = g_small_split_on && a->trans_a && !a->trans_b && nw >= 2 && nw <= 8 && tiles * nw <= 4LL * cu_count();
+  const int nw = (a->K + 16 * U - 1) / (16 * U);
+  const bool split = g_small_split_on && a->trans_a && !a->trans_b && nw >= 2 && nw <= 8 && *tiles * nw <= 4LL * cu_count();
   p.k_per_wave = split ? 16 * U : a->K;
+  *nw_out = split ? nw : 1;
+  return p;
+}
+}  // namespace
+
+// dX = dY W^T and dW = X^T dY of one Dense layer in one launch: both small, the first with both
+// operands readable 16 bytes at a time along k, the second the weight-gradient form.
+bool gemm_small_pair_applies(const vitk_gemm_args *x, const vitk_gemm_args *w) {
+  if (!gemm_small_applies(x) || !gemm_small_applies(w)) return false;
+  if (x->trans_a || !x->trans_b || !w->trans_a || w->trans_b || x->colsum_b != nullptr) return false;
+  bool av, bv;
+  long long tiles;
+  int nw;
+  (void)small_params(x, &av, &bv, &tiles, &nw);
+  return av && bv;
+}
+
+int gemm_small_pair_launch(const vitk_gemm_args *x, const vitk_gemm_args *w, hipStream_t st) {
+  SmallPair pp;
+  bool av, bv;
+  long long t0, t1;
+  int nw0, nw1;
+  pp.first = small_params(x, &av, &bv, &t0, &nw0);
+  pp.second = small_params(w, &av, &bv, &t1, &nw1);
+  pp.tiles0 = (int)t0;
+  pp.groups0 = (int)((t0 + nw1 - 1) / nw1);
+  const dim3 grid((unsigned)(pp.groups0 + t1));
+  if (nw1 > 1) hipLaunchKernelGGL((gemm_small_pair_kernel<8>), grid, dim3(64 * nw1), 0, st, pp);
+  else hipLaunchKernelGGL((gemm_small_pair_kernel<1>), grid, dim3(64), 0, st, pp);
+  return check_launch("vitk_gemm_pair_f32/small");
+}
+
+int gemm_small_launch(const vitk_gemm_args *a, hipStream_t st) {
+  bool av, bv;
+  long long tiles;
+  int nw;
+  SmallParams p = small_params(a, &av, &bv, &tiles, &nw);
+  const bool split = nw > 1;
+  const dim3 grid((unsigned)tiles);
 #define VITK_SMALL(AV_, BV_)                                                                                  \
   if (split) hipLaunchKernelGGL((gemm_small_kernel<AV_, BV_, 8>), grid, dim3(64 * nw), 0, st, p);             \
   else hipLaunchKernelGGL((gemm_small_kernel<AV_, BV_, 1>), grid, dim3(64), 0, st, p);

@@ -47,6 +47,11 @@ struct GemmOpts {
 
 void gemm(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
           int64_t ldb, float *C, int64_t ldc, const GemmOpts &o = GemmOpts());
+// Both products of Dense::backward (src/layers/Dense.cpp:90-98): dW = X^T dY with db = dY.sum(0) from
+// the same launch, and dX = dY W^T with dx_opts' epilogue (vitk_gemm_pair_f32: one launch on the
+// reference's small models, two otherwise).  x {rows,in}, dy {rows,out}, W {in,out} with pitch ldw.
+void dense_backward_gemms(int64_t rows, int64_t in, int64_t out, const float *x, const float *dy, const float *W, int64_t ldw,
+                          float *dW, int64_t lddw, float *db, float *dx, const GemmOpts &dx_opts);
 void colsum(const float *x, int64_t rows, int64_t cols, int64_t ldx, float *out);
 
 }  // namespace vit

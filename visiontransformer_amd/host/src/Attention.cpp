@@ -262,16 +262,9 @@ Tensor MultiHeadAttention::backward(const Tensor &outputGradient) {
 Tensor MultiHeadAttention::projectionBackward(const Tensor &dqkv) {
   const auto &s = inputTensor.getShape();
   const int64_t D = (int64_t)embedding_dim, M = (int64_t)(s[0] * s[1]);
-  const float *dq = dqkv.deviceData();
-  const float *x = inputTensor.deviceData();
-  {
-    GemmOpts o;
-    o.split_k = 0;
-    o.colsum_b = dbqkv.deviceData();
-    vit::gemm(true, false, D, 3 * D, M, x, D, dq, 3 * D, dwqkv.deviceData(), 3 * D, o);
-  }
   Tensor dx = Tensor::deviceEmpty(inputTensor.getShape());
-  vit::gemm(false, true, M, D, 3 * D, dq, 3 * D, wqkv.deviceData(), 3 * D, dx.deviceDataOverwrite(), D);
+  vit::dense_backward_gemms(M, D, 3 * D, inputTensor.deviceData(), dqkv.deviceData(), wqkv.deviceData(), 3 * D,
+                            dwqkv.deviceData(), 3 * D, dbqkv.deviceData(), dx.deviceDataOverwrite(), GemmOpts());
   return dx;
 }
 

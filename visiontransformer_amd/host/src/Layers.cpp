@@ -83,13 +83,15 @@ Tensor Dense::backwardFused(const Tensor &outputGradient, int act, const Tensor 
   if (dy.getSize() != rows * out) throw std::runtime_error("Dense::backward: forma de gradiente incompatible.");
   // dW = X^T dY : contraction over all rows; the library splits it over the chip.  db = dY.sum(0)
   // is accumulated by the same launch from the dY tiles it stages.
-  GemmOpts ow;
-  ow.split_k = 0;
-  ow.colsum_b = biasGradients.deviceData();
-  vit::gemm(true, false, (int64_t)in, (int64_t)out, (int64_t)rows, inputTensor.deviceData(), (int64_t)in,
-            dy.deviceData(), (int64_t)out, weightGradients.deviceData(), (int64_t)weightGradients.getStrides()[0], ow);
-  if (!needInputGrad) return Tensor();
-  // dX = dY W^T
+  if (!needInputGrad) {
+    GemmOpts ow;
+    ow.split_k = 0;
+    ow.colsum_b = biasGradients.deviceData();
+    vit::gemm(true, false, (int64_t)in, (int64_t)out, (int64_t)rows, inputTensor.deviceData(), (int64_t)in,
+              dy.deviceData(), (int64_t)out, weightGradients.deviceData(), (int64_t)weightGradients.getStrides()[0], ow);
+    return Tensor();
+  }
+  // ... together with dX = dY W^T (one launch for both on the reference's small models)
   Tensor dx = Tensor::deviceEmpty(inputTensor.getShape());
   GemmOpts ox;
   if (act == VITK_ACT_GELU_BWD) {
@@ -98,8 +100,10 @@ Tensor Dense::backwardFused(const Tensor &outputGradient, int act, const Tensor 
     ox.aux = const_cast<float *>(preact->deviceData());
     ox.ldaux = (int64_t)in;
   }
-  vit::gemm(false, true, (int64_t)rows, (int64_t)in, (int64_t)out, dy.deviceData(), (int64_t)out, weights.deviceData(),
-            (int64_t)weights.getStrides()[0], dx.deviceDataOverwrite(), (int64_t)in, ox);
+  vit::dense_backward_gemms((int64_t)rows, (int64_t)in, (int64_t)out, inputTensor.deviceData(), dy.deviceData(),
+                            weights.deviceData(), (int64_t)weights.getStrides()[0], weightGradients.deviceData(),
+                            (int64_t)weightGradients.getStrides()[0], biasGradients.deviceData(),
+                            dx.deviceDataOverwrite(), ox);
   return dx;
 }
 

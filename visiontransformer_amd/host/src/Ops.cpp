@@ -1,5 +1,7 @@
 #include "core/Ops.hpp"
 
+#include <algorithm>
+
 namespace vit {
 
 ParamArena::ParamArena(size_t count) : p(std::make_shared<Storage>(count)), g(std::make_shared<Storage>(count)) {
@@ -29,8 +31,8 @@ void ParamArena::take(const std::vector<size_t> &shape, Tensor *param, Tensor *g
   *grad = Tensor(g, shape, strides, off);
 }
 
-void gemm(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
-          int64_t ldb, float *C, int64_t ldc, const GemmOpts &o) {
+static vitk_gemm_args gemm_args(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                                const float *B, int64_t ldb, float *C, int64_t ldc, const GemmOpts &o) {
   vitk_gemm_args g{};
   g.trans_a = trans_a; g.trans_b = trans_b;
   g.M = (int32_t)M; g.N = (int32_t)N; g.K = (int32_t)K;
@@ -43,12 +45,34 @@ void gemm(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const flo
   g.stride_c_outer = o.sc_o; g.stride_c_inner = o.sc_i;
   g.split_k = o.split_k;
   g.colsum_b = o.colsum_b;
+  return g;
+}
+
+void gemm(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
+          int64_t ldb, float *C, int64_t ldc, const GemmOpts &o) {
+  vitk_gemm_args g = gemm_args(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, o);
   const size_t wsb = vitk_gemm_workspace_bytes(&g);
   if (wsb) {
     g.workspace = workspace(wsb);
     g.workspace_bytes = wsb;
   }
   check(vitk_gemm_f32(&g, stream()), "vitk_gemm_f32");
+}
+
+void dense_backward_gemms(int64_t rows, int64_t in, int64_t out, const float *x, const float *dy, const float *W, int64_t ldw,
+                          float *dW, int64_t lddw, float *db, float *dx, const GemmOpts &dx_opts) {
+  GemmOpts ow;
+  ow.split_k = 0;
+  ow.colsum_b = db;
+  vitk_gemm_args gw = gemm_args(true, false, in, out, rows, x, in, dy, out, dW, lddw, ow);
+  vitk_gemm_args gx = gemm_args(false, true, rows, in, out, dy, out, W, ldw, dx, in, dx_opts);
+  // the two launches (if it comes to two) run one after the other on one stream: one workspace serves both
+  const size_t wsb = std::max(vitk_gemm_workspace_bytes(&gw), vitk_gemm_workspace_bytes(&gx));
+  if (wsb) {
+    gw.workspace = gx.workspace = workspace(wsb);
+    gw.workspace_bytes = gx.workspace_bytes = wsb;
+  }
+  check(vitk_gemm_pair_f32(&gx, &gw, stream()), "vitk_gemm_pair_f32");
 }
 
 void colsum(const float *x, int64_t rows, int64_t cols, int64_t ldx, float *out) {

@@ -42,6 +42,7 @@ SIGNATURES = {
     "vitk_last_error": (C.c_char_p, []),
     "vitk_init": (C.c_int, [C.c_int]),
     "vitk_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), _p]),
+    "vitk_gemm_pair_f32": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _p]),
     "vitk_gemm_workspace_bytes": (_sz, [C.POINTER(GemmArgs)]),
     "vitk_gemm_profile_enable": (C.c_int, [C.c_int]),
     "vitk_gemm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -148,13 +149,9 @@ def init(device=0):
     check(dll().vitk_init(device))
 
 
-def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, alpha=1.0,
-         act=ACT_NONE, bias=None, residual=None, ldr=None, aux=None, ldaux=None, batch_outer=1, batch_inner=1,
-         stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), split_k=1, workspace=None, st=None, colsum_b=None,
-         tile=None):
-    """C = epilogue(alpha * op(A) op(B)); see include/vitk.h.  With split_k != 1 and no workspace given,
-    one is allocated with torch (tests only; the host layer passes its own).  tile: None = the
-    library's choice; "64x64", "128x64", "64x128" force that output tile (tests, measurements)."""
+def _gemm_args(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, alpha=1.0,
+               act=ACT_NONE, bias=None, residual=None, ldr=None, aux=None, ldaux=None, batch_outer=1, batch_inner=1,
+               stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), split_k=1, colsum_b=None, tile=None):
     a = GemmArgs()
     a.reserved = {None: 0, "64x64": 1, "128x64": 2, "64x128": 3}[tile]
     a.trans_a, a.trans_b, a.M, a.N, a.K = int(trans_a), int(trans_b), M, N, K
@@ -172,6 +169,11 @@ def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=Non
     a.stride_c_outer, a.stride_c_inner = stride_c
     a.split_k = split_k
     a.colsum_b = ptr(colsum_b)
+    return a
+
+
+def _give_workspace(a, workspace):
+    """Attach `workspace` (or, for tests, a fresh torch buffer) when these arguments need one."""
     need = dll().vitk_gemm_workspace_bytes(C.byref(a))
     keep = None
     if need:
@@ -179,7 +181,25 @@ def gemm(A, B, Cout, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=Non
             import torch
             keep = workspace = torch.empty(need // 4, dtype=torch.float32, device="cuda")
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * 4
+    return keep
+
+
+def gemm(A, B, Cout, M, N, K, *, workspace=None, st=None, **kw):
+    """C = epilogue(alpha * op(A) op(B)); see include/vitk.h.  With split_k != 1 and no workspace given,
+    one is allocated with torch (tests only; the host layer passes its own).  tile: None = the
+    library's choice; "64x64", "128x64", "64x128" force that output tile (tests, measurements)."""
+    a = _gemm_args(A, B, Cout, M, N, K, **kw)
+    keep = _give_workspace(a, workspace)
     check(dll().vitk_gemm_f32(C.byref(a), st if st is not None else stream()))
+    return keep
+
+
+def gemm_pair(dx, dw, st=None):
+    """vitk_gemm_pair_f32: dx and dw are dicts of gemm() arguments (A, B, Cout, M, N, K, ...) of the two
+    products of a Dense backward."""
+    ax, aw = _gemm_args(**dx), _gemm_args(**dw)
+    keep = (_give_workspace(ax, None), _give_workspace(aw, None))
+    check(dll().vitk_gemm_pair_f32(C.byref(ax), C.byref(aw), st if st is not None else stream()))
     return keep
 
 
@@ -206,7 +226,7 @@ def gemm_profile(enable):
 def gemm_profile_read(reset=True):
     """Per kernel variant: dict(name, ms, flops, launches) for variants that were launched."""
     out = []
-    for v in range(52):
+    for v in range(53):
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         check(dll().vitk_gemm_profile_read(v, C.byref(ms), C.byref(fl), C.byref(n), 0))
         if n.value:
