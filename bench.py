@@ -240,6 +240,9 @@ def parse_args(argv):
                     help="dropout rate (0 = the headline/parity configuration; 0.1 adds the device RNG cost)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="seconds after which a self-started multi-rank run is stopped")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0 and the gradient exchange goes through host "
+                         "memory and the gloo group (RCCL refuses two ranks on one device); numbers are not throughput")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, have each report the variables it was given, and stop (no GPU needed)")
     return ap.parse_args(argv)
@@ -284,6 +287,8 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     collectives = world > 1 or args.force_collectives
     if args.through_trainer and world > 1:
@@ -303,7 +308,9 @@ def main():
     host.seed(42)  # identical N(0, 0.02) init on every rank (then broadcast from rank 0 anyway)
     model = host.Model(cfg, patch_mode=vitk.PATCH_IM2COL)
     trainer = host.Trainer(model, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4)
-    if collectives:
+    if collectives and args.share_gpu:
+        transport_errors = dp.init_host_staged()
+    elif collectives:
         dp.init_rccl()
     ddp = dp.NativeDataParallel(model, trainer, bucket_bytes=int(args.bucket_mb * (1 << 20)))
     ddp.broadcast_parameters(0)
@@ -415,7 +422,8 @@ def main():
     # -- so theirs are timed in a pass of the same steps after the timed region.
     events_in_region = cfgd["image_size"] >= 224
     vitk.gemm_profile(events_in_region)
-    if collectives:
+    timing = collectives and not args.share_gpu  # (the exposed-exchange events need the stream-ordered transport)
+    if timing:
         host.comm_timing(True)
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -423,9 +431,11 @@ def main():
     enqueued = time.perf_counter() - t0  # the host has issued every launch; the GPU may still be working
     own = barrier() - t0
     elapsed = time.perf_counter() - t0
-    exposed_ms, exposed_n = host.comm_exposed_ms() if collectives else (0.0, 0)
-    if collectives:
+    exposed_ms, exposed_n = host.comm_exposed_ms() if timing else (0.0, 0)
+    if timing:
         host.comm_timing(False)
+    if collectives and args.share_gpu and transport_errors:
+        raise SystemExit(f"gradient exchange failed: {transport_errors[0]!r}")
     loss, _ = trainer.result()
     if not events_in_region:
         vitk.gemm_profile(True)
@@ -498,7 +508,9 @@ def main():
             out["exposed_comm_ms_per_step"] = max(exposed_per_rank)
             out["exposed_comm_ms_per_step_per_rank"] = exposed_per_rank
             out["config"]["bucket_mb"] = args.bucket_mb
-            out["config"]["communicators"] = "one RCCL communicator (the host layer's); id, barriers and timings over a CPU gloo group"
+            out["config"]["communicators"] = ("rehearsal: ranks share GPU 0, gradients exchanged through host memory over gloo"
+                                              if args.share_gpu else "one RCCL communicator (the host layer's); id, "
+                                              "barriers and timings over a CPU gloo group")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgd, batch)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -217,3 +217,23 @@ def test_bench_starts_its_ranks_itself_and_reports_the_exchange(tmp_path):
     assert out["exposed_comm_ms_per_step"] >= 0 and out["exposed_comm_ms_per_step"] < out["ms_per_step"]
     assert "gradient buckets" in out["config"]["parallelism"]
     assert np.isfinite(out["config"]["final_loss"]) and out["value"] > 0
+
+
+def test_bench_with_two_ranks_end_to_end(tmp_path):
+    """The N > 1 path of bench.py itself on the one GPU of the test box: the parent starts two ranks,
+    they meet over gloo, shard nothing but exchange every gradient bucket (through host memory: RCCL
+    refuses two ranks on one device), and rank 0's line carries both ranks' timings."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "mnist_p14",
+                        "--batch", "32", "--steps", "4", "--warmup", "2", "--bucket-mb", "0.25", "--launch-timeout", "100"],
+                       env=env, capture_output=True, text=True, timeout=110, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["global_batch"] == 64
+    assert len(out["per_rank_ms_per_step"]) == 2 and all(0 < t <= out["ms_per_step"] * 1.001 for t in out["per_rank_ms_per_step"])
+    assert "cpu_baseline" not in out and np.isfinite(out["config"]["final_loss"])
