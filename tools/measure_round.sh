@@ -31,9 +31,12 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = prof ]; then
   export TMPDIR=/tmp
-  for w in vit_b16 vit_s16 vit_ti16; do
+  for w in vit_b16 vit_s16 vit_ti16 blood_p7 mnist_p14; do
     rm -rf "/tmp/kt_$w"
-    run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/kt_$w" -o kt -- python3 "$ROOT/bench.py" --workload $w --no-cpu-baseline --steps 5 --warmup 2 \
+    steps="--steps 5 --warmup 2"
+    [ $w = blood_p7 ] && steps="--steps 50 --warmup 10"
+    [ $w = mnist_p14 ] && steps="--steps 100 --warmup 20"
+    run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/kt_$w" -o kt -- python3 "$ROOT/bench.py" --workload $w --no-cpu-baseline $steps \
         > "$OUT/${TAG}_bench_${w}_under_rocprof.json" 2>> "$OUT/err.log"
     cp "$(find /tmp/kt_$w -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_${w}_kernel_stats.csv" || exit 1
     echo "   kernel stats of $w copied"
