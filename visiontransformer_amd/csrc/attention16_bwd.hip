@@ -25,17 +25,17 @@
 // position in the list of blocks lives in scalar registers, and the row statistics {max * log2 e,
 // 1 / sum, sum_d dO * O} of the (at most two) live heads are prepared once per head in LDS.
 //
-// LDS tile layout: [16 rows][69 floats].  Operand reads by row (A[i = c][k]: row c, column
-// 16g + step) are conflict-free for any odd pitch; reads by column (A[i = c][k]: row 4g + r,
-// column 16 dt + c) want the two lane groups of a half-wave 16 banks apart, which 69 misses for 4
-// lanes of 32 (2-way) -- cheaper than keeping two copies of every tile.
+// LDS tile layout: [16 rows][68 floats].  Operand reads by row (A[i = c][k]: row c, columns
+// 16g .. 16g + 15) are four 16-byte reads per lane, and a pitch of 68 floats puts the eight lanes
+// one cycle serves on all 32 banks; reads by column (A[i = c][k]: row 4g + r, column 16 dt + c)
+// want the two lane groups of a half-wave 16 banks apart, which 4 * 68 = 16 (mod 32) gives.
 #include "common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TP = 69;                    // tile row pitch
+constexpr int TP = 68;                    // tile row pitch (a multiple of 4: rows are 16-byte aligned)
 constexpr int TILE = 16 * TP;             // one 16 x 64 tile
 constexpr int SLOT = 2 * TILE;            // Q tile + dO tile of one head
 constexpr int STAGE = 2 * SLOT;           // two heads may be live in one round
@@ -43,7 +43,7 @@ constexpr int PBP = 68, PB = 16 * PBP;    // one wave's partial dQ tile [query][
 constexpr int TBP = 20, TB = 16 * TBP;    // one wave's dS transpose buffer [query][key]
 constexpr int MAXN = 256;
 constexpr int F_RING = 0, F_PB = F_RING + 2 * STAGE, F_TB = F_PB + 2 * 4 * PB, F_ST = F_TB + 4 * TB;  // (partial tiles: two sets)
-constexpr int F_TOTAL = F_ST + 2 * 3 * MAXN;  // statistics: [head parity][max2 | 1/sum | dsum][query]
+constexpr int F_TOTAL = F_ST + 2 * 2 * MAXN;  // statistics: [head parity][max * log2 e + log2 sum | dsum][query]
 
 struct Bwd16Params {
   const float *q, *k, *v;   // element (b, n, h, d) at ptr[(b*N + n)*ld + h*dh + d]
@@ -160,27 +160,22 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
   };
   auto store_tiles = [&](int stage, bool two) {
     float *d = st_dst + stage * STAGE;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      d[e] = lq[0][e];
-      d[TILE + e] = lg[0][e];
-    }
+    *reinterpret_cast<f32x4 *>(d) = lq[0];
+    *reinterpret_cast<f32x4 *>(d + TILE) = lg[0];
     if (two) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        d[SLOT + e] = lq[1][e];
-        d[SLOT + TILE + e] = lg[1][e];
-      }
+      *reinterpret_cast<f32x4 *>(d + SLOT) = lq[1];
+      *reinterpret_cast<f32x4 *>(d + SLOT + TILE) = lg[1];
     }
   };
 
-  // Row statistics of head h into its LDS slot (h & 1): max * log2(e), 1 / sum, sum_d dO * O.
+  // Row statistics of head h into its LDS slot (h & 1): max * log2(e) + log2(sum), so that
+  // P = exp2(s * scale * log2 e - that) (rows past the sequence: P = 0), and sum_d dO * O.
   // All 256 threads; 7 query tiles of loads in flight at a time.
   auto fill_stats = [&](int h) {
     int oq, oo, og;
     offs(h, &oq, &oo, &og);
     const __amdgpu_buffer_rsrc_t rg_ = rsrc(p.dout, oo, bytes_o), ro_ = rsrc(p.o, oo, bytes_o);
-    float *dst = stat + (h & 1) * 3 * MAXN;
+    float *dst = stat + (h & 1) * 2 * MAXN;
     const float *sp = p.stats + (long long)(head0 + h) * p.N * 2;
     constexpr int G = 7;
     for (int t0 = 0; t0 < nqt; t0 += G) {
@@ -199,9 +194,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
         if ((threadIdx.x & 15) == 0 && row < MAXN && t0 + i < nqt) {
           const bool ok = row < p.N;
           const float mx = ok ? sp[2 * row] : 0.f, sm = ok ? sp[2 * row + 1] : 1.f;
-          dst[row] = mx * 1.44269504088896340736f;
-          dst[MAXN + row] = ok ? 1.0f / sm : 0.f;
-          dst[2 * MAXN + row] = ok ? part : 0.f;
+          dst[row] = ok ? __builtin_fmaf(mx, 1.44269504088896340736f, __log2f(sm)) : 1e30f;
+          dst[MAXN + row] = ok ? part : 0.f;
         }
       }
     }
@@ -220,31 +214,48 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
   }
   int stage = 0;  // ring stage of the tile about to be used = set of partial tiles about to be written
 
-  // The partial dQ tiles of a step are summed at the start of the NEXT step (one barrier per step:
-  // the sets alternate), possibly the first step of the next round: what that needs is kept here.
-  bool pend = false;
+  // dQ leaves two steps behind the step that forms its partial tiles.  The partial tiles a step
+  // puts in LDS are summed at the END of the next step (one barrier per step: the sets alternate),
+  // together with what the head's earlier rounds stored, which that step loads at its start; the
+  // sums stay in registers across the barrier and are stored FIRST thing in the step after, ahead
+  // of its loads.  (The counter that waits for memory go by counts loads and stores in issue
+  // order: a store issued behind a step's loads is waited for along with them, in every step; a
+  // loaded value carried across the barrier costs a full wait at the top of the loop.)  All of it
+  // runs in EVERY step, the first ones included -- nothing pending: no tiles to sum, and an offset
+  // outside the descriptor makes the load return zeros and drops the store -- because a load that
+  // some path leaves unconsumed also costs a full wait at the top of the loop.
+  bool pend_acc = false;
   int pend_k0 = 0, pend_na = 0, pend_row0 = 0;
   int pend_lo = 0, pend_hi = 0;
-  f32x4 pend_old = zero4();
-  auto reduce_pending = [&](int set) {
-    // sum in wave order; thread t owns query row t/16, columns 4*(t%16) .. (rows past the sequence
-    // and columns past the head fall outside the descriptor: the store is dropped)
+  unsigned pend_voff = kOutside;
+  f32x4 out_lo = zero4(), out_hi = zero4();  // sums on their way out (second head: only where a round spans two)
+  int out_off_lo = 0, out_off_hi = 0, out_so = 0;
+  unsigned out_voff = kOutside;
+  bool out_two = false;
+  auto load_pending_old = [&]() {
+    return buf_quad(rsrc(p.dq, pend_lo, bytes_g), pend_acc ? pend_voff : kOutside, pend_row0 * (tile_g / 16));
+  };
+  auto write_out = [&]() {
+    // thread t owns query row t/16, columns 4*(t%16) .. (rows past the sequence and columns past
+    // the head fall outside the descriptor: the store is dropped)
+    buf_store_quad(out_lo, rsrc(p.dq, out_off_lo, bytes_g), out_voff, out_so);
+    if (out_two) buf_store_quad(out_hi, rsrc(p.dq, out_off_hi, bytes_g), out_voff, out_so);
+  };
+  auto sum_pending = [&](int set, const f32x4 pend_old) {  // in wave order
     const float *src = lds + F_PB + set * 4 * PB + sr * PBP + sc;
-    const int so = pend_row0 * (tile_g / 16);
     if (pend_k0 == 4) {  // the usual round: four blocks of one head
       const f32x4 p0 = *reinterpret_cast<const f32x4 *>(src), p1 = *reinterpret_cast<const f32x4 *>(src + PB);
       const f32x4 p2 = *reinterpret_cast<const f32x4 *>(src + 2 * PB), p3 = *reinterpret_cast<const f32x4 *>(src + 3 * PB);
-      buf_store_quad((((pend_old + p0) + p1) + p2) + p3, rsrc(p.dq, pend_lo, bytes_g), sv_g, so);
-      return;
+      out_lo = (((pend_old + p0) + p1) + p2) + p3;
+      out_two = false;
+    } else {
+      out_lo = pend_old;
+      for (int w = 0; w < pend_k0; ++w) out_lo += *reinterpret_cast<const f32x4 *>(src + w * PB);
+      out_two = pend_k0 < pend_na;  // the round's second head: always its first round
+      out_hi = zero4();
+      for (int w = pend_k0; w < pend_na; ++w) out_hi += *reinterpret_cast<const f32x4 *>(src + w * PB);
     }
-    f32x4 sum = pend_old;
-    for (int w = 0; w < pend_k0; ++w) sum += *reinterpret_cast<const f32x4 *>(src + w * PB);
-    buf_store_quad(sum, rsrc(p.dq, pend_lo, bytes_g), sv_g, so);
-    if (pend_k0 < pend_na) {  // the round's second head: always its first round
-      f32x4 sum2 = zero4();
-      for (int w = pend_k0; w < pend_na; ++w) sum2 += *reinterpret_cast<const f32x4 *>(src + w * PB);
-      buf_store_quad(sum2, rsrc(p.dq, pend_hi, bytes_g), sv_g, so);
-    }
+    out_off_lo = pend_lo, out_off_hi = pend_hi, out_so = pend_row0 * (tile_g / 16), out_voff = pend_voff;
   };
 
   for (int round = 0; round < rounds; ++round) {
@@ -272,9 +283,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
     int oq_lo, oo_lo, og_lo, oq_hi, oo_hi, og_hi;  // element offsets of the round's head(s)
     offs(lo.h, &oq_lo, &oo_lo, &og_lo);
     offs(lo.h + 1, &oq_hi, &oo_hi, &og_hi);
-    const __amdgpu_buffer_rsrc_t rdq_lo = rsrc(p.dq, og_lo, bytes_g);
     const bool key_ok = 16 * my.q + c < p.N;
-    const float *mystat = stat + (my.h & 1) * 3 * MAXN + 4 * g;
+    const float *mystat = stat + (my.h & 1) * 2 * MAXN + 4 * g;
 
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -284,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
       const bool last = qt + 1 == nqt;
       // next in the stream: this round's next query tile, or the next round's first
       const bool stream_on = !last || more_rounds;
+      write_out();
       if (stream_on) {
         int a0 = oq_lo, b0 = oo_lo, a1_ = oq_hi, b1 = oo_hi, unused;
         if (last) {  // the tile that opens the next round
@@ -292,9 +303,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
         }
         load_tiles(a0, b0, a1_, b1, last ? ntwo : two, last ? 0 : qt + 1);
       }
-      f32x4 old = zero4();
-      if (accumulate) old = buf_quad(rdq_lo, sv_g, qt * tile_g);
-      if (pend) reduce_pending(stage ^ 1);
+      const f32x4 old = load_pending_old();
 
       if (active) {
         const float *qs = lds + F_RING + stage * STAGE + slot * SLOT, *gs = qs + TILE;
@@ -302,23 +311,25 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
         // S = Q K^T and dP = dO V^T, both [query][key]
         f32x4 s = zero4(), dp = zero4();
         {
-          float qa[16], ga[16];
+          f32x4 qa[4], ga[4];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) qa[i] = qs[a1 + i], ga[i] = gs[a1 + i];
+          for (int i = 0; i < 4; ++i) {
+            qa[i] = *reinterpret_cast<const f32x4 *>(qs + a1 + 4 * i);
+            ga[i] = *reinterpret_cast<const f32x4 *>(gs + a1 + 4 * i);
+          }
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i], kf[i / 4][i % 4], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i], vf[i / 4][i % 4], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i / 4][i % 4], kf[i / 4][i % 4], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i / 4][i % 4], vf[i / 4][i % 4], dp, 0, 0, 0);
           }
         }
         // P from the saved statistics; dS = P (dP - dsum) scale
         const f32x4 m2 = *reinterpret_cast<const f32x4 *>(mystat + 16 * qt);
-        const f32x4 li = *reinterpret_cast<const f32x4 *>(mystat + MAXN + 16 * qt);
-        const f32x4 ds_ = *reinterpret_cast<const f32x4 *>(mystat + 2 * MAXN + 16 * qt);
+        const f32x4 ds_ = *reinterpret_cast<const f32x4 *>(mystat + MAXN + 16 * qt);
         f32x4 pr, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -m2[r])) * li[r];
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -m2[r]));
           pr[r] = key_ok ? e : 0.f;
           ds[r] = (pr[r] * (dp[r] - ds_[r])) * p.scale;
           tb[(4 * g + r) * TBP + c] = ds[r];  // dS[query][key], read back transposed below
@@ -347,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
         for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4 *>(pb + c * PBP + 16 * dt + 4 * g) = dq[dt];
       }
       if (stream_on) store_tiles(stage ^ 1, last ? ntwo : two);
-      pend = true, pend_k0 = k0, pend_na = na, pend_row0 = 16 * qt, pend_lo = og_lo, pend_hi = og_hi, pend_old = old;
+      sum_pending(stage ^ 1, old);
+      pend_voff = sv_g, pend_acc = accumulate, pend_k0 = k0, pend_na = na, pend_row0 = 16 * qt, pend_lo = og_lo, pend_hi = og_hi;
       stage ^= 1;
       __syncthreads();  // this step's partial tiles and the next step's query tile are in LDS
     }
@@ -387,7 +399,9 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
     for (int i = 0; i < 4; ++i) kf[i] = nkf[i], vf[i] = nvf[i], kt[i] = nkt[i];
     lo = nlo, my = nmy, two = ntwo;
   }
-  if (pend) reduce_pending(stage ^ 1);
+  write_out();
+  sum_pending(stage ^ 1, load_pending_old());
+  write_out();
 }
 
 int g_bwd16_mode = 1;  // 0 = off, 1 = on (heads per workgroup from the device size), n >= 2 = on with n heads per workgroup
