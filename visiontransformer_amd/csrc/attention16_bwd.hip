@@ -43,7 +43,7 @@ constexpr int PBP = 68, PB = 16 * PBP;    // one wave's partial dQ tile [query][
 constexpr int TBP = 20, TB = 16 * TBP;    // one wave's dS transpose buffer [query][key]
 constexpr int MAXN = 256;
 constexpr int F_RING = 0, F_PB = F_RING + 2 * STAGE, F_TB = F_PB + 2 * 4 * PB, F_ST = F_TB + 4 * TB;  // (partial tiles: two sets)
-constexpr int F_TOTAL = F_ST + 2 * 2 * MAXN;  // statistics: [head parity][max * log2 e + log2 sum | dsum][query]
+constexpr int F_TOTAL = F_ST + 2 * 3 * MAXN;  // statistics: [head parity][max2 | 1/sum | dsum][query]
 
 struct Bwd16Params {
   const float *q, *k, *v;   // element (b, n, h, d) at ptr[(b*N + n)*ld + h*dh + d]
@@ -168,14 +168,13 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
     }
   };
 
-  // Row statistics of head h into its LDS slot (h & 1): max * log2(e) + log2(sum), so that
-  // P = exp2(s * scale * log2 e - that) (rows past the sequence: P = 0), and sum_d dO * O.
+  // Row statistics of head h into its LDS slot (h & 1): max * log2(e), 1 / sum, sum_d dO * O.
   // All 256 threads; 7 query tiles of loads in flight at a time.
   auto fill_stats = [&](int h) {
     int oq, oo, og;
     offs(h, &oq, &oo, &og);
     const __amdgpu_buffer_rsrc_t rg_ = rsrc(p.dout, oo, bytes_o), ro_ = rsrc(p.o, oo, bytes_o);
-    float *dst = stat + (h & 1) * 2 * MAXN;
+    float *dst = stat + (h & 1) * 3 * MAXN;
     const float *sp = p.stats + (long long)(head0 + h) * p.N * 2;
     constexpr int G = 7;
     for (int t0 = 0; t0 < nqt; t0 += G) {
@@ -194,8 +193,9 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
         if ((threadIdx.x & 15) == 0 && row < MAXN && t0 + i < nqt) {
           const bool ok = row < p.N;
           const float mx = ok ? sp[2 * row] : 0.f, sm = ok ? sp[2 * row + 1] : 1.f;
-          dst[row] = ok ? __builtin_fmaf(mx, 1.44269504088896340736f, __log2f(sm)) : 1e30f;
-          dst[MAXN + row] = ok ? part : 0.f;
+          dst[row] = mx * 1.44269504088896340736f;
+          dst[MAXN + row] = ok ? 1.0f / sm : 0.f;
+          dst[2 * MAXN + row] = ok ? part : 0.f;
         }
       }
     }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
     offs(lo.h, &oq_lo, &oo_lo, &og_lo);
     offs(lo.h + 1, &oq_hi, &oo_hi, &og_hi);
     const bool key_ok = 16 * my.q + c < p.N;
-    const float *mystat = stat + (my.h & 1) * 2 * MAXN + 4 * g;
+    const float *mystat = stat + (my.h & 1) * 3 * MAXN + 4 * g;
 
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -325,11 +325,12 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd16_kernel(const Bwd16Params p)
         }
         // P from the saved statistics; dS = P (dP - dsum) scale
         const f32x4 m2 = *reinterpret_cast<const f32x4 *>(mystat + 16 * qt);
-        const f32x4 ds_ = *reinterpret_cast<const f32x4 *>(mystat + MAXN + 16 * qt);
+        const f32x4 li = *reinterpret_cast<const f32x4 *>(mystat + MAXN + 16 * qt);
+        const f32x4 ds_ = *reinterpret_cast<const f32x4 *>(mystat + 2 * MAXN + 16 * qt);
         f32x4 pr, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -m2[r]));
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -m2[r])) * li[r];
           pr[r] = key_ok ? e : 0.f;
           ds[r] = (pr[r] * (dp[r] - ds_[r])) * p.scale;
           tb[(4 * g + r) * TBP + c] = ds[r];  // dS[query][key], read back transposed below
