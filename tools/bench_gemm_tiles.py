@@ -1,7 +1,8 @@
 """Tile-shape choice on the contractions of ViT-Ti / ViT-S (M = 256 x 197 rows): the library's plan
 against each tile forced (vitk_gemm_args.reserved: 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128), plain
 epilogue.  Weight gradients (TN, K = 50 432) keep the plan's split count.
-    PYTHONPATH=. python tools/bench_gemm_tiles.py [substring of the shape names]"""
+    PYTHONPATH=. python tools/bench_gemm_tiles.py [substring of the shape names] [--rows M]
+(--rows 8704: the same contractions at the row count of the 17-token model, batch 512)"""
 import ctypes as C
 import sys
 
@@ -11,6 +12,10 @@ from visiontransformer_amd import vitk
 
 vitk.init(0)
 M = 50432
+if "--rows" in sys.argv:
+    i = sys.argv.index("--rows")
+    M = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 # (name, m, n, k, trans_a, trans_b)
 shapes = [("Ti qkv", M, 576, 192, 0, 0), ("Ti out", M, 192, 192, 0, 0), ("Ti ffn1", M, 768, 192, 0, 0),
           ("Ti ffn2", M, 192, 768, 0, 0), ("Ti dx ffn1", M, 192, 768, 0, 1), ("Ti dx ffn2", M, 768, 192, 0, 1),
