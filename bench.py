@@ -29,6 +29,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -446,6 +447,9 @@ def main():
     prof = vitk.gemm_profile_read()
 
     elapsed = max_over_ranks(elapsed)
+    # (after the timed region) every rank trained on its own images: the parameters only stay the
+    # same on all of them if every gradient went through the exchange
+    params_crc = [int(v) for v in every_rank(zlib.crc32(model.get_params().tobytes()))] if collectives else []
     per_rank_ms = [round(1e3 * v / args.steps, 3) for v in every_rank(own)]
     exposed_per_rank = [round(v, 3) for v in every_rank(exposed_ms / max(exposed_n, 1))]
     ms_per_step = 1e3 * elapsed / args.steps
@@ -507,6 +511,7 @@ def main():
             out["n_ranks_seen"] = host.comm_world()
             out["exposed_comm_ms_per_step"] = max(exposed_per_rank)
             out["exposed_comm_ms_per_step_per_rank"] = exposed_per_rank
+            out["ranks_hold_identical_parameters"] = len(set(params_crc)) == 1
             out["config"]["bucket_mb"] = args.bucket_mb
             out["config"]["communicators"] = ("rehearsal: ranks share GPU 0, gradients exchanged through host memory over gloo"
                                               if args.share_gpu else "one RCCL communicator (the host layer's); id, "

@@ -215,7 +215,7 @@ def test_bench_starts_its_ranks_itself_and_reports_the_exchange(tmp_path):
     assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1
     assert len(out["per_rank_ms_per_step"]) == 1 and 0 < out["per_rank_ms_per_step"][0] <= out["ms_per_step"] * 1.001
     assert out["exposed_comm_ms_per_step"] >= 0 and out["exposed_comm_ms_per_step"] < out["ms_per_step"]
-    assert "gradient buckets" in out["config"]["parallelism"]
+    assert "gradient buckets" in out["config"]["parallelism"] and out["ranks_hold_identical_parameters"] is True
     assert np.isfinite(out["config"]["final_loss"]) and out["value"] > 0
 
 
@@ -237,3 +237,5 @@ def test_bench_with_two_ranks_end_to_end(tmp_path):
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["global_batch"] == 64
     assert len(out["per_rank_ms_per_step"]) == 2 and all(0 < t <= out["ms_per_step"] * 1.001 for t in out["per_rank_ms_per_step"])
     assert "cpu_baseline" not in out and np.isfinite(out["config"]["final_loss"])
+    # the two ranks trained on different images: equal parameters mean every gradient was exchanged
+    assert out["ranks_hold_identical_parameters"] is True
